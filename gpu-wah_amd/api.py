@@ -1,0 +1,279 @@
+"""ctypes binding of libwah_hip.so (C ABI: include/wah.h).
+
+PyTorch is used only as plumbing for device memory and streams in the
+device-pointer helpers; no torch type crosses the ABI (plain pointers, sizes
+and a hipStream_t passed as void*).
+"""
+import collections
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libwah_hip.so")
+
+Timings = collections.namedtuple("Timings", "to_device_ms device_ms from_device_ms")
+
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_f32p = ctypes.POINTER(ctypes.c_float)
+_vp = ctypes.c_void_p
+_u64 = ctypes.c_uint64
+_sz = ctypes.c_size_t
+_int = ctypes.c_int
+
+# name -> (restype, argtypes): every extern "C" symbol include/wah.h declares
+ABI_SYMBOLS = {
+    "wah_compress": (_vp, [_vp, _u64, _u64p, _f32p, _f32p, _f32p]),
+    "wah_decompress": (_vp, [_vp, _u64, _u64p, _f32p, _f32p, _f32p]),
+    "wah_free": (None, [_vp]),
+    "wah_max_compressed_words": (_u64, [_u64]),
+    "wah_decoded_words": (_u64, [_u64]),
+    "wah_compress_workspace_bytes": (_sz, [_u64]),
+    "wah_decompress_workspace_bytes": (_sz, [_u64, _u64]),
+    "wah_compress_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_compress_device_indexed": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _sz, _vp]),
+    "wah_compress_status": (_int, [_vp, _vp]),
+    "wah_decompress_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_decompress_scan_device": (_int, [_vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_decompress_expand_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_decompress_status": (_int, [_vp, _vp]),
+    "wah_gen_uniform_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
+    "wah_gen_clustered_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
+    "wah_copy_device": (_int, [_vp, _vp, _u64, _vp]),
+    "wah_last_error": (ctypes.c_char_p, []),
+    "wah_version": (ctypes.c_char_p, []),
+}
+# the reference's own C++-linkage symbols (compress.h:12-18, decompress.h:11-17)
+CXX_SYMBOLS = ("_Z8compressPjyPyPfS1_S1_", "_Z10decompressPjyPyPfS1_S1_")
+
+
+class WahError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def build(force=False, verbose=False):
+    """Compile libwah_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("wah.h", "wah_gen.h", "compress.h", "decompress.h")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        cmd = ["make", "-C", _HERE, "libwah_hip.so"] + (["-B"] if force else [])
+        subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; fail loudly when it is missing (there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise WahError(f"{_LIB_PATH} not found: build it with __graft_entry__.build() or "
+                           f"`make -C {_HERE}` -- the HIP extension is required, there is no CPU fallback")
+        handle = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in ABI_SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def version():
+    return lib().wah_version().decode()
+
+
+def _err():
+    return lib().wah_last_error().decode()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise WahError(f"{what} failed (code {rc}): {_err()}")
+
+
+def max_compressed_words(n_words):
+    return int(lib().wah_max_compressed_words(int(n_words)))
+
+
+def decoded_words(n_groups):
+    return int(lib().wah_decoded_words(int(n_groups)))
+
+
+def threshold_for(p):
+    """Generator threshold for bit density p (include/wah_gen.h)."""
+    return min(int(p * 2**32), 2**32)
+
+
+# --------------------------------------------------------------------------
+# host-pointer operators: the reference's API
+# --------------------------------------------------------------------------
+def _host_call(fn, data):
+    a = np.ascontiguousarray(data, dtype=np.uint32)
+    n_out = _u64(0)
+    t = [ctypes.c_float(0.0) for _ in range(3)]
+    ptr = fn(a.ctypes.data if a.size else None, a.size, ctypes.byref(n_out), ctypes.byref(t[0]), ctypes.byref(t[1]),
+             ctypes.byref(t[2]))
+    if not ptr:
+        raise WahError(f"{fn.__name__} returned NULL: {_err()}")
+    try:
+        out = np.ctypeslib.as_array(ctypes.cast(ptr, _u32p), shape=(max(n_out.value, 1),))[: n_out.value].copy()
+    finally:
+        lib().wah_free(ptr)
+    return out, Timings(*(x.value for x in t))
+
+
+def compress(data, with_timings=False):
+    """compress() of the reference (compress.cu:41-209): host bitmap words in, compressed words out."""
+    out, t = _host_call(lib().wah_compress, data)
+    return (out, t) if with_timings else out
+
+
+def decompress(comp, with_timings=False):
+    """decompress() of the reference (decompress.cu:18-141): returns the ceil(31*G/32) decoded words."""
+    out, t = _host_call(lib().wah_decompress, comp)
+    return (out, t) if with_timings else out
+
+
+# --------------------------------------------------------------------------
+# device-pointer operators (torch tensors as device memory; int32 storage)
+# --------------------------------------------------------------------------
+def _torch():
+    import torch
+
+    if not torch.cuda.is_available():
+        raise WahError("no GPU visible: the device-pointer API needs an MI355X")
+    return torch
+
+
+def _stream_ptr(torch, stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)
+
+
+def _as_words(torch, t):
+    if t.dtype not in (torch.int32, torch.uint32) or not t.is_cuda or not t.is_contiguous():
+        raise WahError("expected a contiguous 32-bit integer CUDA tensor")
+    return t
+
+
+class DeviceCompressor:
+    """Reusable workspace + output for compressing bitmaps of up to `n_words` words in HBM.
+
+    Replaces the per-call cudaMalloc/cudaFree of compress.cu:89-103,191-193: nothing is
+    allocated inside run(), so it can be timed (and graph-captured) as pure device work.
+    """
+
+    def __init__(self, n_words, device="cuda:0", indexed=False):
+        torch = _torch()
+        self.n_words = int(n_words)
+        self.capacity = max_compressed_words(self.n_words)
+        self.ws_bytes = int(lib().wah_compress_workspace_bytes(self.n_words))
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.out = torch.empty(max(self.capacity, 1), dtype=torch.int32, device=device)
+        self.count = torch.zeros(1, dtype=torch.int64, device=device)
+        n_seg = (self.capacity + 1023) // 1024
+        self.seg_offsets = torch.zeros(n_seg + 1, dtype=torch.int64, device=device) if indexed else None
+
+    def run(self, d_in, n_words=None, stream=None):
+        """Enqueue one compress pass; returns nothing (read .count / .out after synchronising)."""
+        torch = _torch()
+        _as_words(torch, d_in)
+        n = self.n_words if n_words is None else int(n_words)
+        if n > self.n_words or n > d_in.numel():
+            raise WahError("input larger than this compressor was sized for")
+        sp = _stream_ptr(torch, stream)
+        if self.seg_offsets is None:
+            rc = lib().wah_compress_device(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, self.count.data_ptr(),
+                                           self.workspace.data_ptr(), self.ws_bytes, sp)
+        else:
+            rc = lib().wah_compress_device_indexed(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity,
+                                                   self.count.data_ptr(), self.seg_offsets.data_ptr(),
+                                                   self.workspace.data_ptr(), self.ws_bytes, sp)
+        _check(rc, "wah_compress_device")
+
+    def status(self, stream=None):
+        torch = _torch()
+        _check(lib().wah_compress_status(self.workspace.data_ptr(), _stream_ptr(torch, stream)), "compress")
+
+    def result(self, stream=None):
+        """Synchronise, check the launch status, return the compressed words as a device tensor view."""
+        self.status(stream)
+        return self.out[: int(self.count.item())]
+
+
+class DeviceDecompressor:
+    """Reusable workspace + output for decoding streams of up to `c_words` words into `out_capacity` words."""
+
+    def __init__(self, c_words, out_capacity_words, device="cuda:0"):
+        torch = _torch()
+        self.c_words = int(c_words)
+        self.capacity = int(out_capacity_words)
+        self.ws_bytes = int(lib().wah_decompress_workspace_bytes(self.c_words, self.capacity))
+        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.out = torch.empty(max(self.capacity, 1), dtype=torch.int32, device=device)
+        self.info = torch.zeros(2, dtype=torch.int64, device=device)  # [decoded words, groups]
+
+    def run(self, d_comp, c_words=None, stream=None):
+        torch = _torch()
+        _as_words(torch, d_comp)
+        c = self.c_words if c_words is None else int(c_words)
+        if c > self.c_words or c > d_comp.numel():
+            raise WahError("stream larger than this decompressor was sized for")
+        rc = lib().wah_decompress_device(d_comp.data_ptr(), c, self.out.data_ptr(), self.capacity, self.info.data_ptr(),
+                                         self.workspace.data_ptr(), self.ws_bytes, _stream_ptr(torch, stream))
+        _check(rc, "wah_decompress_device")
+
+    def status(self, stream=None):
+        torch = _torch()
+        _check(lib().wah_decompress_status(self.workspace.data_ptr(), _stream_ptr(torch, stream)), "decompress")
+
+    def result(self, stream=None):
+        self.status(stream)
+        return self.out[: int(self.info[0].item())]
+
+
+def compress_device(d_in):
+    """One-shot device compress: int32 CUDA tensor in, compressed int32 CUDA tensor out."""
+    c = DeviceCompressor(d_in.numel(), device=d_in.device)
+    c.run(d_in)
+    return c.result().clone()
+
+
+def decompress_device(d_comp, out_capacity_words):
+    d = DeviceDecompressor(d_comp.numel(), out_capacity_words, device=d_comp.device)
+    d.run(d_comp)
+    return d.result().clone()
+
+
+def gen_uniform_device(n_words, seed, p, device="cuda:0"):
+    """Bernoulli(p) bitmap generated in HBM (bit-exact definition: include/wah_gen.h)."""
+    torch = _torch()
+    out = torch.empty(max(int(n_words), 1), dtype=torch.int32, device=device)
+    _check(lib().wah_gen_uniform_device(out.data_ptr(), int(n_words), int(seed), threshold_for(p),
+                                        _stream_ptr(torch)), "wah_gen_uniform_device")
+    return out[: int(n_words)]
+
+
+def gen_clustered_device(n_words, seed, mean_run_bits=4096, device="cuda:0"):
+    torch = _torch()
+    out = torch.empty(max(int(n_words), 1), dtype=torch.int32, device=device)
+    _check(lib().wah_gen_clustered_device(out.data_ptr(), int(n_words), int(seed), threshold_for(1.0 / mean_run_bits),
+                                          _stream_ptr(torch)), "wah_gen_clustered_device")
+    return out[: int(n_words)]
+
+
+def copy_device(d_in, d_out):
+    torch = _torch()
+    _check(lib().wah_copy_device(d_in.data_ptr(), d_out.data_ptr(), int(d_in.numel()), _stream_ptr(torch)),
+           "wah_copy_device")

@@ -1,0 +1,499 @@
+// wah_api.hip -- the C ABI of include/wah.h and the C++-linkage drop-ins of
+// include/compress.h / include/decompress.h, on top of the kernels.
+//
+// Host orchestration replacing compress.cu:41-209 and decompress.cu:18-141:
+// same phases and the same three timings, but the device phase is
+// memset(control block) + kernel(s) with no allocation, no blocking 8-byte
+// read-back in the middle and no library scan.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/compress.h"
+#include "../../include/decompress.h"
+#include "../../include/wah.h"
+#include "wah_internal.hpp"
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+void set_err(const char *what, hipError_t e = hipSuccess) {
+    if (e != hipSuccess)
+        std::snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    else
+        std::snprintf(g_err, sizeof g_err, "%s", what);
+}
+
+inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+inline size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+struct CompressLayout {
+    uint64_t n_groups, n_segments, n_tiles;
+    size_t ctrl_off, desc_off, total;
+};
+
+CompressLayout compress_layout(uint64_t n_words) {
+    CompressLayout l;
+    l.n_groups = wah_max_compressed_words(n_words);
+    l.n_segments = ceil_div(l.n_groups, wah::kSegGroups);
+    l.n_tiles = ceil_div(l.n_segments, (uint64_t)wah::kCompressWaves);
+    l.ctrl_off = 0;
+    l.desc_off = wah::kCtlWords * sizeof(uint32_t);
+    l.total = round256(l.desc_off + (l.n_tiles + 1) * sizeof(uint64_t));
+    return l;
+}
+
+struct DecodeLayout {
+    uint64_t n_tiles, max_segments, seg_capacity;
+    size_t ctrl_off, desc_off, seg_word_off, seg_skip_off, total, zero_bytes;
+};
+
+DecodeLayout decode_layout(uint64_t c_words, uint64_t out_capacity_words) {
+    DecodeLayout l;
+    l.n_tiles = ceil_div(c_words, (uint64_t)wah::kScanTileWords);
+    // G groups decode to ceil(31 G / 32) words: at most floor(32 cap / 31) groups fit
+    const uint64_t max_groups = out_capacity_words * 32u / 31u;
+    l.max_segments = ceil_div(max_groups, wah::kSegGroups);
+    l.seg_capacity = l.max_segments + 1;
+    l.ctrl_off = 0;
+    l.desc_off = wah::kCtlWords * sizeof(uint32_t);
+    l.zero_bytes = round256(l.desc_off + (l.n_tiles + 1) * sizeof(uint64_t));
+    l.seg_word_off = l.zero_bytes;
+    l.seg_skip_off = round256(l.seg_word_off + l.seg_capacity * sizeof(uint64_t));
+    l.total = round256(l.seg_skip_off + l.seg_capacity * sizeof(uint32_t));
+    return l;
+}
+
+int read_status(void *d_workspace, void *stream) {
+    uint32_t err = 0;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(&err, static_cast<uint32_t *>(d_workspace) + wah::kCtlError, sizeof err,
+                                  hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        set_err("status read-back", e);
+        return WAH_ERR_HIP;
+    }
+    if (err & wah::kErrTimeout) {
+        set_err("in-kernel bounded wait expired");
+        return WAH_ERR_TIMEOUT;
+    }
+    if (err & wah::kErrStream) {
+        set_err("malformed compressed stream");
+        return WAH_ERR_STREAM;
+    }
+    if (err & wah::kErrCapacity) {
+        set_err("output capacity too small");
+        return WAH_ERR_CAPACITY;
+    }
+    return WAH_OK;
+}
+
+// RAII bundle for the host-pointer paths: frees whatever was allocated, like the error
+// exits of compress.cu:89-114, and owns the timing events.
+struct HostCall {
+    void *bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int nbufs = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    ~HostCall() {
+        release();
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    void release() {
+        for (int i = 0; i < nbufs; ++i)
+            if (bufs[i]) (void)hipFree(bufs[i]);
+        nbufs = 0;
+    }
+    bool alloc(void **p, size_t bytes, const char *what) {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+        if (e != hipSuccess) {
+            set_err(what, e);
+            std::fprintf(stderr, "wah: could not allocate %s (%zu bytes): %s\n", what, bytes, hipGetErrorString(e));
+            return false;
+        }
+        bufs[nbufs++] = *p;
+        return true;
+    }
+    bool init() {
+        return hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
+    }
+    void start() { (void)hipEventRecord(ev[0], nullptr); }
+    float stop() {
+        float ms = 0.f;
+        (void)hipEventRecord(ev[1], nullptr);
+        (void)hipEventSynchronize(ev[1]);
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        return ms;
+    }
+};
+
+bool hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    set_err(what, e);
+    std::fprintf(stderr, "wah: %s failed: %s\n", what, hipGetErrorString(e));
+    return false;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *wah_last_error(void) { return g_err; }
+const char *wah_version(void) { return "wah-mi355x 0.1 gfx950"; }
+void wah_free(void *p) { std::free(p); }
+
+uint64_t wah_max_compressed_words(uint64_t n_words) { return (32u * n_words + 30u) / 31u; }
+uint64_t wah_decoded_words(uint64_t n_groups) { return (31u * n_groups + 31u) / 32u; }
+
+size_t wah_compress_workspace_bytes(uint64_t n_words) { return compress_layout(n_words).total; }
+size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_words) {
+    return decode_layout(c_words, out_capacity_words).total;
+}
+
+int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
+                                uint64_t *d_out_words, uint64_t *d_segment_offsets, void *d_workspace,
+                                size_t workspace_bytes, void *stream) {
+    g_err[0] = 0;
+    if (!d_out_words || !d_workspace || (n_words && (!d_in || !d_out))) {
+        set_err("null pointer");
+        return WAH_ERR_ARG;
+    }
+    if (n_words >= (1ull << 40) || (reinterpret_cast<uintptr_t>(d_in) & 3u) || (reinterpret_cast<uintptr_t>(d_workspace) & 255u)) {
+        set_err("size out of range or misaligned pointer");
+        return WAH_ERR_ARG;
+    }
+    const CompressLayout l = compress_layout(n_words);
+    if (workspace_bytes < l.total) {
+        set_err("workspace too small");
+        return WAH_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(d_workspace);
+    hipError_t e = hipMemsetAsync(ws, 0, l.total, s);
+    if (e != hipSuccess) {
+        set_err("hipMemsetAsync", e);
+        return WAH_ERR_HIP;
+    }
+    if (n_words == 0) {
+        e = hipMemsetAsync(d_out_words, 0, sizeof(uint64_t), s);
+        if (e == hipSuccess && d_segment_offsets) e = hipMemsetAsync(d_segment_offsets, 0, sizeof(uint64_t), s);
+        if (e != hipSuccess) {
+            set_err("hipMemsetAsync", e);
+            return WAH_ERR_HIP;
+        }
+        return WAH_OK;
+    }
+    wah::CompressArgs a;
+    a.in = d_in;
+    a.n_words = n_words;
+    a.n_groups = l.n_groups;
+    a.n_segments = l.n_segments;
+    a.n_tiles = l.n_tiles;
+    a.out = d_out;
+    a.out_capacity = out_capacity_words;
+    a.out_words = d_out_words;
+    a.seg_offsets = d_segment_offsets;
+    a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
+    a.desc = reinterpret_cast<uint64_t *>(ws + l.desc_off);
+    a.aligned16 = aligned16(d_in) ? 1 : 0;
+    static thread_local int grid_cache = 0;
+    if (!grid_cache) grid_cache = wah::compress_grid(~0ull);
+    const int grid = (uint64_t)grid_cache < l.n_tiles ? grid_cache : (int)l.n_tiles;
+    e = wah::launch_compress(a, grid, s);
+    if (e != hipSuccess) {
+        set_err("compress kernel launch", e);
+        return WAH_ERR_HIP;
+    }
+    return WAH_OK;
+}
+
+int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
+                        uint64_t *d_out_words, void *d_workspace, size_t workspace_bytes, void *stream) {
+    return wah_compress_device_indexed(d_in, n_words, d_out, out_capacity_words, d_out_words, nullptr, d_workspace,
+                                       workspace_bytes, stream);
+}
+
+int wah_compress_status(void *d_workspace, void *stream) { return read_status(d_workspace, stream); }
+int wah_decompress_status(void *d_workspace, void *stream) { return read_status(d_workspace, stream); }
+
+static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
+                         uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream, bool do_scan,
+                         bool do_expand) {
+    g_err[0] = 0;
+    if (!d_out_info || !d_workspace || (c_words && !d_comp) || (do_expand && out_capacity_words && !d_out)) {
+        set_err("null pointer");
+        return WAH_ERR_ARG;
+    }
+    if (c_words >= (1ull << 40) || (reinterpret_cast<uintptr_t>(d_comp) & 3u) || (reinterpret_cast<uintptr_t>(d_workspace) & 255u)) {
+        set_err("size out of range or misaligned pointer");
+        return WAH_ERR_ARG;
+    }
+    const DecodeLayout l = decode_layout(c_words, out_capacity_words);
+    if (workspace_bytes < l.total) {
+        set_err("workspace too small");
+        return WAH_ERR_WORKSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(d_workspace);
+    hipError_t e = hipSuccess;
+    if (do_scan) {
+        e = hipMemsetAsync(ws, 0, l.zero_bytes, s);
+        if (e == hipSuccess && c_words == 0) e = hipMemsetAsync(d_out_info, 0, 2 * sizeof(uint64_t), s);
+        if (e != hipSuccess) {
+            set_err("hipMemsetAsync", e);
+            return WAH_ERR_HIP;
+        }
+    }
+    if (c_words == 0) return WAH_OK;
+    if (do_scan) {
+        wah::ScanArgs a;
+        a.comp = d_comp;
+        a.c_words = c_words;
+        a.n_tiles = l.n_tiles;
+        a.info = d_out_info;
+        a.seg_word = reinterpret_cast<uint64_t *>(ws + l.seg_word_off);
+        a.seg_skip = reinterpret_cast<uint32_t *>(ws + l.seg_skip_off);
+        a.seg_capacity = l.seg_capacity;
+        a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
+        a.desc = reinterpret_cast<uint64_t *>(ws + l.desc_off);
+        a.aligned16 = aligned16(d_comp) ? 1 : 0;
+        static thread_local int grid_cache = 0;
+        if (!grid_cache) grid_cache = wah::decode_scan_grid(~0ull);
+        const int grid = (uint64_t)grid_cache < l.n_tiles ? grid_cache : (int)l.n_tiles;
+        e = wah::launch_decode_scan(a, grid, s);
+        if (e != hipSuccess) {
+            set_err("decode scan kernel launch", e);
+            return WAH_ERR_HIP;
+        }
+    }
+    if (do_expand) {
+        wah::ExpandArgs x;
+        x.comp = d_comp;
+        x.c_words = c_words;
+        x.out = d_out;
+        x.out_capacity = out_capacity_words;
+        x.info = d_out_info;
+        x.seg_word = reinterpret_cast<const uint64_t *>(ws + l.seg_word_off);
+        x.seg_skip = reinterpret_cast<const uint32_t *>(ws + l.seg_skip_off);
+        x.seg_capacity = l.seg_capacity;
+        x.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
+        e = wah::launch_decode_expand(x, l.max_segments, s);
+        if (e != hipSuccess) {
+            set_err("decode expand kernel launch", e);
+            return WAH_ERR_HIP;
+        }
+    }
+    return WAH_OK;
+}
+
+int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
+                          uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream) {
+    return decode_common(d_comp, c_words, d_out, out_capacity_words, d_out_info, d_workspace, workspace_bytes, stream,
+                         true, true);
+}
+
+int wah_decompress_scan_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_out_info, void *d_workspace,
+                               size_t workspace_bytes, void *stream) {
+    // sized for "no output": the segment index is not kept, only the totals
+    return decode_common(d_comp, c_words, nullptr, 0, d_out_info, d_workspace, workspace_bytes, stream, true, false);
+}
+
+int wah_decompress_expand_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out,
+                                 uint64_t out_capacity_words, uint64_t *d_out_info, void *d_workspace,
+                                 size_t workspace_bytes, void *stream) {
+    return decode_common(d_comp, c_words, d_out, out_capacity_words, d_out_info, d_workspace, workspace_bytes, stream,
+                         false, true);
+}
+
+int wah_gen_uniform_device(uint32_t *d_out, uint64_t n_words, uint64_t seed, uint64_t threshold, void *stream) {
+    hipError_t e = wah::launch_gen_uniform(d_out, n_words, seed, threshold, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        set_err("generator launch", e);
+        return WAH_ERR_HIP;
+    }
+    return WAH_OK;
+}
+
+int wah_gen_clustered_device(uint32_t *d_out, uint64_t n_words, uint64_t seed, uint64_t threshold, void *stream) {
+    hipError_t e = wah::launch_gen_clustered(d_out, n_words, seed, threshold, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        set_err("generator launch", e);
+        return WAH_ERR_HIP;
+    }
+    return WAH_OK;
+}
+
+int wah_copy_device(const uint32_t *d_in, uint32_t *d_out, uint64_t n_words, void *stream) {
+    hipError_t e = wah::launch_copy(d_in, d_out, n_words, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        set_err("copy launch", e);
+        return WAH_ERR_HIP;
+    }
+    return WAH_OK;
+}
+
+// ---------------------------------------------------------------------------
+// host-pointer entry points (the reference's API)
+// ---------------------------------------------------------------------------
+uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *out_words, float *t_to_device_ms,
+                       float *t_device_ms, float *t_from_device_ms) {
+    g_err[0] = 0;
+    if (n_words && !data_host) {
+        set_err("null input");
+        std::fprintf(stderr, "wah: compress() called with a null input\n");
+        return nullptr;
+    }
+    HostCall hc;
+    if (!hc.init()) {
+        set_err("hipEventCreate failed (no usable GPU?)");
+        std::fprintf(stderr, "wah: %s\n", g_err);
+        return nullptr;
+    }
+    float t_in = 0.f, t_dev = 0.f, t_out = 0.f;
+
+    // phase 1: allocate + H2D (compress.cu:57-120)
+    hc.start();
+    const uint64_t cap = wah_max_compressed_words(n_words);
+    const size_t ws_bytes = wah_compress_workspace_bytes(n_words);
+    void *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr, *d_cnt = nullptr;
+    if (!hc.alloc(&d_in, n_words * sizeof(uint32_t), "space for the data")) return nullptr;
+    if (!hc.alloc(&d_out, cap * sizeof(uint32_t), "space for the compressed output")) return nullptr;
+    if (!hc.alloc(&d_ws, ws_bytes, "workspace")) return nullptr;
+    if (!hc.alloc(&d_cnt, sizeof(uint64_t), "output size")) return nullptr;
+    if (n_words && !hip_ok(hipMemcpy(d_in, data_host, n_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
+        return nullptr;
+    t_in = hc.stop();
+
+    // phase 2: device work (compress.cu:125-172)
+    hc.start();
+    int rc = wah_compress_device(static_cast<uint32_t *>(d_in), n_words, static_cast<uint32_t *>(d_out), cap,
+                                 static_cast<uint64_t *>(d_cnt), d_ws, ws_bytes, nullptr);
+    if (rc == WAH_OK) rc = wah_compress_status(d_ws, nullptr);
+    if (rc != WAH_OK) {
+        std::fprintf(stderr, "wah: compress failed: %s\n", g_err);
+        return nullptr;
+    }
+    uint64_t c = 0;
+    if (!hip_ok(hipMemcpy(&c, d_cnt, sizeof c, hipMemcpyDeviceToHost), "copy output size")) return nullptr;
+    t_dev = hc.stop();
+
+    // phase 3: D2H + free (compress.cu:177-202)
+    hc.start();
+    uint32_t *host = static_cast<uint32_t *>(std::malloc((c ? c : 1) * sizeof(uint32_t)));
+    if (!host) {
+        set_err("host malloc failed");
+        return nullptr;
+    }
+    if (c && !hip_ok(hipMemcpy(host, d_out, c * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy final output")) {
+        std::free(host);
+        return nullptr;
+    }
+    hc.release();
+    t_out = hc.stop();
+
+    if (out_words) *out_words = c;
+    if (t_to_device_ms) *t_to_device_ms = t_in;
+    if (t_device_ms) *t_device_ms = t_dev;
+    if (t_from_device_ms) *t_from_device_ms = t_out;
+    return host;
+}
+
+uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *out_words, float *t_to_device_ms,
+                         float *t_device_ms, float *t_from_device_ms) {
+    g_err[0] = 0;
+    if (c_words && !comp_host) {
+        set_err("null input");
+        std::fprintf(stderr, "wah: decompress() called with a null input\n");
+        return nullptr;
+    }
+    HostCall hc;
+    if (!hc.init()) {
+        set_err("hipEventCreate failed (no usable GPU?)");
+        std::fprintf(stderr, "wah: %s\n", g_err);
+        return nullptr;
+    }
+    float t_in = 0.f, t_dev = 0.f, t_out = 0.f;
+
+    // phase 1: allocate + H2D (decompress.cu:34-54)
+    hc.start();
+    void *d_comp = nullptr, *d_info = nullptr, *d_ws0 = nullptr;
+    const size_t ws0 = wah_decompress_workspace_bytes(c_words, 0);
+    if (!hc.alloc(&d_comp, c_words * sizeof(uint32_t), "space for the compressed data")) return nullptr;
+    if (!hc.alloc(&d_info, 2 * sizeof(uint64_t), "output size")) return nullptr;
+    if (!hc.alloc(&d_ws0, ws0, "scan workspace")) return nullptr;
+    if (c_words && !hip_ok(hipMemcpy(d_comp, comp_host, c_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
+        return nullptr;
+    t_in = hc.stop();
+
+    // phase 2: device work (decompress.cu:56-122): size scan, allocate, scan + expand
+    hc.start();
+    int rc = wah_decompress_scan_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint64_t *>(d_info), d_ws0,
+                                        ws0, nullptr);
+    if (rc == WAH_OK) rc = wah_decompress_status(d_ws0, nullptr);
+    uint64_t info[2] = {0, 0};
+    if (rc == WAH_OK && !hip_ok(hipMemcpy(info, d_info, sizeof info, hipMemcpyDeviceToHost), "copy output size"))
+        rc = WAH_ERR_HIP;
+    if (rc != WAH_OK) {
+        std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
+        return nullptr;
+    }
+    const uint64_t n_out = info[0], groups = info[1];
+    void *d_out = nullptr, *d_ws = nullptr;
+    const size_t ws = wah_decompress_workspace_bytes(c_words, n_out);
+    if (!hc.alloc(&d_out, n_out * sizeof(uint32_t), "space for the result")) return nullptr;
+    if (!hc.alloc(&d_ws, ws, "workspace")) return nullptr;
+    rc = wah_decompress_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(d_out), n_out,
+                               static_cast<uint64_t *>(d_info), d_ws, ws, nullptr);
+    if (rc == WAH_OK) rc = wah_decompress_status(d_ws, nullptr);
+    if (rc != WAH_OK) {
+        std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
+        return nullptr;
+    }
+    t_dev = hc.stop();
+
+    // phase 3: D2H + free (decompress.cu:124-131).  The reference hands back a buffer of G words
+    // (one per group) of which ceil(31 G / 32) are meaningful; we keep the size and zero the rest.
+    hc.start();
+    uint32_t *host = static_cast<uint32_t *>(std::calloc(groups ? groups : 1, sizeof(uint32_t)));
+    if (!host) {
+        set_err("host malloc failed");
+        return nullptr;
+    }
+    if (n_out && !hip_ok(hipMemcpy(host, d_out, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy final output")) {
+        std::free(host);
+        return nullptr;
+    }
+    hc.release();
+    t_out = hc.stop();
+
+    if (out_words) *out_words = n_out;
+    if (t_to_device_ms) *t_to_device_ms = t_in;
+    if (t_device_ms) *t_device_ms = t_dev;
+    if (t_from_device_ms) *t_from_device_ms = t_out;
+    return host;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// The reference's own symbols, C++ linkage (compress.h:12-18, decompress.h:11-17):
+// _Z8compressPjyPyPfS1_S1_ and _Z10decompressPjyPyPfS1_S1_.
+// ---------------------------------------------------------------------------
+unsigned int *compress(unsigned int *data_cpu, unsigned long long int dataSize, unsigned long long int *outputSize,
+                       float *pTransferToDeviceTime, float *pCompressionTime, float *ptranserFromDeviceTime) {
+    uint64_t c = 0;
+    uint32_t *r = wah_compress(data_cpu, dataSize, &c, pTransferToDeviceTime, pCompressionTime, ptranserFromDeviceTime);
+    if (r && outputSize) *outputSize = c;
+    return r;
+}
+
+unsigned int *decompress(unsigned int *data, unsigned long long int dataSize, unsigned long long int *outSize,
+                         float *pTransferToDeviceTime, float *pCompressionTime, float *ptranserFromDeviceTime) {
+    uint64_t n = 0;
+    uint32_t *r = wah_decompress(data, dataSize, &n, pTransferToDeviceTime, pCompressionTime, ptranserFromDeviceTime);
+    if (r && outSize) *outSize = n;
+    return r;
+}

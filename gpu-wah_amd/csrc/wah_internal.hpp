@@ -1,0 +1,97 @@
+// wah_internal.hpp -- declarations shared by the kernel TU and the C-ABI TU.
+//
+// gfx950 / CDNA4 only: 64-lane wavefronts, 8 XCDs with private L2s.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wah {
+
+// ---- wire format (reference const.h:3-16) ---------------------------------
+constexpr uint32_t kOnes31 = 0x7FFFFFFFu;    // ONES31
+constexpr uint32_t kFillZero = 0x80000000u;  // BIT31
+constexpr uint32_t kFillOne = 0xC0000000u;   // BIT3130
+constexpr uint32_t kCountMask = 0x3FFFFFFFu; // BIT30 - 1 (kernels.cu:300)
+
+// ---- segment geometry (kernels.cu:68: one CUDA block = 1024 groups) ------
+constexpr uint32_t kSegWords = 992;
+constexpr uint32_t kSegGroups = 1024;
+constexpr uint32_t kSteps = 16; // 64 groups (one wavefront) per step
+
+// ---- inter-workgroup control block (uint32 words, zeroed before each launch)
+constexpr uint32_t kShards = 8;          // tile-ticket counters
+constexpr uint32_t kCtlStart = 0;        // arrival ticket -> virtual workgroup id
+constexpr uint32_t kCtlShard0 = 16;      // shard i at kCtlShard0 + 16*i (own 64-B line)
+constexpr uint32_t kCtlError = 160;      // sticky error bits
+constexpr uint32_t kCtlWords = 256;      // 1 KiB
+constexpr uint32_t kErrTimeout = 1u;     // a bounded look-back spin expired
+constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity
+constexpr uint32_t kErrStream = 4u;      // malformed compressed stream
+
+// ---- tile descriptor of the decoupled look-back: {status:2, value:62} -----
+constexpr unsigned kStatusShift = 62;
+constexpr uint64_t kStatusAggregate = 1ull << kStatusShift;
+constexpr uint64_t kStatusPrefix = 2ull << kStatusShift;
+constexpr uint64_t kValueMask = (1ull << kStatusShift) - 1;
+
+// ---- compress geometry: one wavefront owns one segment --------------------
+constexpr int kCompressWaves = 8; // segments per tile (workgroup = 512 threads)
+
+// ---- decode scan geometry -------------------------------------------------
+constexpr int kScanThreads = 256;
+constexpr int kScanWordsPerThread = 16;
+constexpr int kScanTileWords = kScanThreads * kScanWordsPerThread; // 4096
+constexpr int kExpandWaves = 4;                                    // segments per workgroup
+
+struct CompressArgs {
+    const uint32_t *in;
+    uint64_t n_words;
+    uint64_t n_groups;
+    uint64_t n_segments;
+    uint64_t n_tiles;
+    uint32_t *out;
+    uint64_t out_capacity;
+    uint64_t *out_words;   // device scalar: C
+    uint64_t *seg_offsets; // optional, n_segments + 1 entries
+    uint32_t *ctrl;        // kCtlWords
+    uint64_t *desc;        // n_tiles
+    int aligned16;
+};
+
+struct ScanArgs {
+    const uint32_t *comp;
+    uint64_t c_words;
+    uint64_t n_tiles;
+    uint64_t *info;      // [0] decoded words, [1] groups
+    uint64_t *seg_word;  // per output segment: index of the word holding its first group
+    uint32_t *seg_skip;  // ... and how many of that word's groups belong to earlier segments
+    uint64_t seg_capacity;
+    uint32_t *ctrl;
+    uint64_t *desc;
+    int aligned16;
+};
+
+struct ExpandArgs {
+    const uint32_t *comp;
+    uint64_t c_words;
+    uint32_t *out;
+    uint64_t out_capacity;
+    const uint64_t *info;
+    const uint64_t *seg_word;
+    const uint32_t *seg_skip;
+    uint64_t seg_capacity;
+    uint32_t *ctrl;
+};
+
+// launchers (wah_kernels.hip)
+hipError_t launch_compress(const CompressArgs &a, int grid, hipStream_t s);
+int compress_grid(uint64_t n_tiles);
+hipError_t launch_decode_scan(const ScanArgs &a, int grid, hipStream_t s);
+int decode_scan_grid(uint64_t n_tiles);
+hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t max_segments, hipStream_t s);
+hipError_t launch_gen_uniform(uint32_t *out, uint64_t n, uint64_t seed, uint64_t thr, hipStream_t s);
+hipError_t launch_gen_clustered(uint32_t *out, uint64_t n, uint64_t seed, uint64_t thr, hipStream_t s);
+hipError_t launch_copy(const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t s);
+
+} // namespace wah

@@ -1,0 +1,144 @@
+/*
+ * wah.h -- C ABI of the MI355X-native WAH bitmap compressor / decompressor.
+ *
+ * This is the drop-in boundary for the reference's hot path.  Every entry point
+ * is `extern "C"`, takes plain pointers and sizes, and names the reference
+ * interface it replaces.  The reference's own two symbols have C++ linkage
+ * (compress.h:12-18, decompress.h:11-17 carry no extern "C"); the library also
+ * exports those, declared in include/compress.h and include/decompress.h, so
+ * the reference's source.cpp / tests.cpp link against libwah_hip.so unchanged.
+ *
+ * Units: all sizes are in 32-bit words unless a name says bytes
+ * (compress.cu:35-36, decompress.cu:12-13).
+ *
+ * Wire format (reference const.h:3-16, kernels.cu:79,244-249,298-354):
+ * 31-bit groups of the LSB-first bit stream; literal = group (bit31 = 0);
+ * fill = 0x80000000 | bit<<30 | count; fills are maximal inside a segment of
+ * 1024 groups (= 992 input words) and never cross a segment boundary.
+ */
+#ifndef WAH_H_
+#define WAH_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WAH_SEGMENT_WORDS 992u   /* compress.cu:62  blockCount = dataSize / (31*32) */
+#define WAH_SEGMENT_GROUPS 1024u /* kernels.cu:68   one (32,32) CUDA block          */
+
+/* status codes of the device-pointer API (0 = success) */
+#define WAH_OK 0
+#define WAH_ERR_ARG (-1)      /* null / misaligned pointer, size out of range        */
+#define WAH_ERR_WORKSPACE (-2) /* workspace too small                                 */
+#define WAH_ERR_HIP (-3)      /* a HIP runtime call failed (see wah_last_error())    */
+#define WAH_ERR_CAPACITY (-4) /* output buffer too small (reported by wah_*_status)  */
+#define WAH_ERR_TIMEOUT (-5)  /* an in-kernel bounded wait expired                   */
+#define WAH_ERR_STREAM (-6)   /* malformed compressed stream                         */
+
+/* ------------------------------------------------------------------------- *
+ * Host-pointer entry points: the reference's API.
+ * ------------------------------------------------------------------------- */
+
+/* Replaces compress() -- compress.h:12-18, compress.cu:41-209.
+ * data_host: caller-owned host memory, read only, n_words words.
+ * Returns a malloc()ed host buffer of *out_words compressed words (release
+ * with free() or wah_free()), or NULL on error (message on stderr;
+ * compress.cu:89-114 prints and returns NULL).  out_words and the three
+ * timing pointers may be NULL (timeMeasuring.h:27-28).  Timings are
+ * milliseconds from device events: (alloc + H2D), (device work), (D2H + free)
+ * -- compress.cu:117-120,169-172,199-202. */
+uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *out_words, float *t_to_device_ms,
+                       float *t_device_ms, float *t_from_device_ms);
+
+/* Replaces decompress() -- decompress.h:11-17, decompress.cu:18-141.
+ * comp_host: c_words compressed words.  Returns a malloc()ed buffer holding G
+ * words (G = number of 31-bit groups, decompress.cu:127) of which the first
+ * *out_words = ceil(31*G/32) are the bitmap (decompress.cu:84-93); the rest
+ * are zero.  NULL on error. */
+uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *out_words, float *t_to_device_ms,
+                         float *t_device_ms, float *t_from_device_ms);
+
+/* free() for buffers returned above (source.cpp:108-109, tests.h:22 use free()). */
+void wah_free(void *p);
+
+/* ------------------------------------------------------------------------- *
+ * Sizes.
+ * ------------------------------------------------------------------------- */
+
+/* ceil(32*n/31): number of 31-bit groups == worst-case compressed size
+ * (compress.cu:74-81 maxExpectedSize). */
+uint64_t wah_max_compressed_words(uint64_t n_words);
+
+/* ceil(31*G/32): words a stream of G groups decodes to (decompress.cu:84-93). */
+uint64_t wah_decoded_words(uint64_t n_groups);
+
+/* Scratch the device-pointer calls need (bytes; 256-byte aligned pointer). */
+size_t wah_compress_workspace_bytes(uint64_t n_words);
+size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_words);
+
+/* ------------------------------------------------------------------------- *
+ * Device-pointer entry points (inputs and outputs resident in HBM, caller's
+ * stream, no allocation, no host synchronisation -- graph capturable).  These
+ * replace the kernel + scan sections of the reference hosts:
+ *   compress.cu:129-166  compressData -> exclusive_scan -> moveData
+ *   decompress.cu:66-115 getCounts -> exclusive_scan -> decompressWords -> mergeWords
+ * `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ * ------------------------------------------------------------------------- */
+
+/* d_in: n_words words, 16-byte aligned.  d_out: room for out_capacity_words
+ * (wah_max_compressed_words(n) always suffices).  d_out_words: one device
+ * uint64 that receives C.  Result status is left in the workspace; read it
+ * with wah_compress_status() after the stream has been synchronised. */
+int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
+                        uint64_t *d_out_words, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Optional side output: when d_segment_offsets != NULL it receives, for every
+ * 992-word segment s, the index of its first compressed word
+ * (n_segments + 1 entries, the last one = C).  This is the reference's scanned
+ * blockCounts array (compress.cu:146) kept instead of thrown away. */
+int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
+                                uint64_t *d_out_words, uint64_t *d_segment_offsets, void *d_workspace,
+                                size_t workspace_bytes, void *stream);
+
+/* Synchronises `stream`, returns WAH_OK or the error a compress launch recorded. */
+int wah_compress_status(void *d_workspace, void *stream);
+
+/* d_comp: c_words compressed words, 16-byte aligned.  d_out: room for
+ * out_capacity_words decoded words.  d_out_info: two device uint64:
+ * [0] = ceil(31*G/32) decoded words, [1] = G groups. */
+int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
+                          uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* First half of the above only (getCounts + scan): fills d_out_info so a
+ * caller that does not know the decoded size can allocate, then call
+ * wah_decompress_device (which repeats the scan) or _expand_device. */
+int wah_decompress_scan_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_out_info, void *d_workspace,
+                               size_t workspace_bytes, void *stream);
+int wah_decompress_expand_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out,
+                                 uint64_t out_capacity_words, uint64_t *d_out_info, void *d_workspace,
+                                 size_t workspace_bytes, void *stream);
+
+int wah_decompress_status(void *d_workspace, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Benchmark support: synthetic bitmaps generated in HBM (include/wah_gen.h
+ * states the bit-exact definition; replaces tests.cpp:42-64), and a plain
+ * 16-byte-per-lane copy used as the on-box HBM ceiling.
+ * ------------------------------------------------------------------------- */
+int wah_gen_uniform_device(uint32_t *d_out, uint64_t n_words, uint64_t seed, uint64_t threshold, void *stream);
+int wah_gen_clustered_device(uint32_t *d_out, uint64_t n_words, uint64_t seed, uint64_t threshold, void *stream);
+int wah_copy_device(const uint32_t *d_in, uint32_t *d_out, uint64_t n_words, void *stream);
+
+/* Last error text of the calling thread ("" if none). */
+const char *wah_last_error(void);
+
+/* Library / build identification, e.g. "wah-mi355x 0.1 gfx950". */
+const char *wah_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WAH_H_ */

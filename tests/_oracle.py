@@ -105,6 +105,30 @@ class Oracle:
         a = np.ascontiguousarray(data, dtype=np.uint32)
         return int(self.lib.wah_oracle_group(_ptr(a), a.size, g))
 
+    def time_round_trip(self, data, threads=1, reps=2):
+        """Best-of-`reps` wall times (compress_s, decompress_s) on pre-touched buffers (CPU baseline leg)."""
+        import time
+
+        a = np.ascontiguousarray(data, dtype=np.uint32)
+        out = np.zeros(self.max_words(a.size) + 1, np.uint32)
+        out.fill(1)  # touch every page: first-touch faults are not part of the algorithm
+        back = np.zeros(a.size + 2, np.uint32)
+        back.fill(1)
+        best_c = best_d = float("inf")
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            if threads > 1:
+                c = int(self.lib.wah_oracle_compress_mt(_ptr(a), a.size, _ptr(out), int(threads)))
+            else:
+                c = int(self.lib.wah_oracle_compress(_ptr(a), a.size, _ptr(out)))
+            t1 = time.perf_counter()
+            n = int(self.lib.wah_oracle_decompress(_ptr(out), c, _ptr(back)))
+            t2 = time.perf_counter()
+            best_c = min(best_c, t1 - t0)
+            best_d = min(best_d, t2 - t1)
+        assert np.array_equal(back[: a.size], a) and n >= a.size
+        return best_c, best_d, c
+
     # --- generators (same bits as the HIP generator kernels; include/wah_gen.h)
     def gen_uniform(self, n_words, seed, p):
         out = np.empty(max(n_words, 1), np.uint32)
