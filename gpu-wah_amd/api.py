@@ -80,6 +80,13 @@ def lib():
         if not os.path.exists(_LIB_PATH):
             raise WahError(f"{_LIB_PATH} not found: build it with __graft_entry__.build() or "
                            f"`make -C {_HERE}` -- the HIP extension is required, there is no CPU fallback")
+        # PyTorch-ROCm ships its own libamdhip64.so (same soname).  Import it first when it is installed, so
+        # that this process has ONE HIP runtime: loading ours first makes torch map a second copy, and the
+        # second runtime to initialise cannot create events or streams.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = ctypes.CDLL(_LIB_PATH)
         for name, (res, args) in ABI_SYMBOLS.items():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol

@@ -172,7 +172,7 @@ __device__ __forceinline__ void stage_segment(const CompressArgs &a, u64 seg, u3
 }
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void compress_kernel(const CompressArgs a) {
+__global__ __launch_bounds__(WAVES * 64, 8) void compress_kernel(const CompressArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_seg[WAVES][kSegLdsWords];
     __shared__ u32 s_count[WAVES];
     __shared__ u64 s_tile;
