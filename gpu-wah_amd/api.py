@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libwah_hip.so")
+# WAH_LIB_PATH selects another build of the same library (tools/ use it for the diagnostic build)
+_LIB_PATH = os.environ.get("WAH_LIB_PATH") or os.path.join(_HERE, "libwah_hip.so")
 
 Timings = collections.namedtuple("Timings", "to_device_ms device_ms from_device_ms")
 

@@ -31,23 +31,26 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 struct CompressLayout {
     uint64_t n_groups, n_segments, n_tiles;
-    size_t ctrl_off, desc_off, total;
+    size_t ctrl_off, desc_off, block_off, total;
 };
 
 CompressLayout compress_layout(uint64_t n_words) {
     CompressLayout l;
     l.n_groups = wah_max_compressed_words(n_words);
     l.n_segments = ceil_div(l.n_groups, wah::kSegGroups);
-    l.n_tiles = ceil_div(l.n_segments, (uint64_t)wah::kCompressWaves);
+    l.n_tiles = ceil_div(l.n_segments, (uint64_t)wah::compress_workers());
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
-    l.total = round256(l.desc_off + (l.n_tiles + 1) * sizeof(uint64_t));
+    // generation rows: rows of round_up(G, 4) granules for G resident workgroups (G is only known after the
+    // census): at most n_tiles + 3 * generations + 3 <= 4 * n_tiles + 8 granules
+    l.block_off = l.desc_off;
+    l.total = round256(l.desc_off + (4 * l.n_tiles + 8) * sizeof(uint32_t));
     return l;
 }
 
 struct DecodeLayout {
     uint64_t n_tiles, max_segments, seg_capacity;
-    size_t ctrl_off, desc_off, seg_word_off, seg_skip_off, total, zero_bytes;
+    size_t ctrl_off, desc_off, block_off, seg_word_off, seg_skip_off, total, zero_bytes;
 };
 
 DecodeLayout decode_layout(uint64_t c_words, uint64_t out_capacity_words) {
@@ -59,7 +62,8 @@ DecodeLayout decode_layout(uint64_t c_words, uint64_t out_capacity_words) {
     l.seg_capacity = l.max_segments + 1;
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
-    l.zero_bytes = round256(l.desc_off + (l.n_tiles + 1) * sizeof(uint64_t));
+    l.block_off = round256(l.desc_off + (l.n_tiles + 1) * sizeof(uint64_t));
+    l.zero_bytes = round256(l.block_off + (l.n_tiles / 32 + 2) * sizeof(uint64_t));
     l.seg_word_off = l.zero_bytes;
     l.seg_skip_off = round256(l.seg_word_off + l.seg_capacity * sizeof(uint64_t));
     l.total = round256(l.seg_skip_off + l.seg_capacity * sizeof(uint32_t));
@@ -139,6 +143,14 @@ bool hip_ok(hipError_t e, const char *what) {
 
 } // namespace
 
+int wah::compress_workers() {
+    static const int w = [] {
+        const char *e = std::getenv("WAH_WORKERS");
+        return (e && std::atoi(e) == 15) ? 15 : wah::kCompressWavesDefault;
+    }();
+    return w;
+}
+
 extern "C" {
 
 const char *wah_last_error(void) { return g_err; }
@@ -172,7 +184,17 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(d_workspace);
-    hipError_t e = hipMemsetAsync(ws, 0, l.total, s);
+    // first call on a device: residency census of the compress kernel (one extra launch + sync, then cached)
+    const int workers = wah::compress_workers();
+    const int resident = n_words ? wah::compress_grid(workers, reinterpret_cast<uint32_t *>(ws), s) : 1;
+    if (resident < 1) {
+        set_err("residency census failed", hipGetLastError());
+        return WAH_ERR_HIP;
+    }
+    const uint64_t grid64 = (uint64_t)resident < l.n_tiles ? (uint64_t)resident : (l.n_tiles ? l.n_tiles : 1);
+    const uint64_t generations = (l.n_tiles + grid64 - 1) / grid64;
+    const size_t used = round256(l.desc_off + (generations * ((grid64 + 3) & ~3ull) + 8) * sizeof(uint32_t));
+    hipError_t e = hipMemsetAsync(ws, 0, used < l.total ? used : l.total, s);
     if (e != hipSuccess) {
         set_err("hipMemsetAsync", e);
         return WAH_ERR_HIP;
@@ -189,20 +211,19 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
     wah::CompressArgs a;
     a.in = d_in;
     a.n_words = n_words;
-    a.n_groups = l.n_groups;
-    a.n_segments = l.n_segments;
-    a.n_tiles = l.n_tiles;
+    a.n_segments = (uint32_t)l.n_segments;
+    a.n_tiles = (uint32_t)l.n_tiles;
+    a.fast_segments = aligned16(d_in) ? (uint32_t)(n_words / wah::kSegWords) : 0u;
+    a.last_segment_groups = (uint32_t)(l.n_groups - (l.n_segments - 1) * wah::kSegGroups);
     a.out = d_out;
     a.out_capacity = out_capacity_words;
     a.out_words = d_out_words;
     a.seg_offsets = d_segment_offsets;
     a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
-    a.desc = reinterpret_cast<uint64_t *>(ws + l.desc_off);
-    a.aligned16 = aligned16(d_in) ? 1 : 0;
-    static thread_local int grid_cache = 0;
-    if (!grid_cache) grid_cache = wah::compress_grid(~0ull);
-    const int grid = (uint64_t)grid_cache < l.n_tiles ? grid_cache : (int)l.n_tiles;
-    e = wah::launch_compress(a, grid, s);
+    a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
+    a.census = 0;
+    const int grid = (int)grid64;
+    e = wah::launch_compress(workers, a, grid, s);
     if (e != hipSuccess) {
         set_err("compress kernel launch", e);
         return WAH_ERR_HIP;
@@ -259,6 +280,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         a.seg_capacity = l.seg_capacity;
         a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
         a.desc = reinterpret_cast<uint64_t *>(ws + l.desc_off);
+        a.block_desc = reinterpret_cast<uint64_t *>(ws + l.block_off);
         a.aligned16 = aligned16(d_comp) ? 1 : 0;
         static thread_local int grid_cache = 0;
         if (!grid_cache) grid_cache = wah::decode_scan_grid(~0ull);

@@ -24,6 +24,7 @@ constexpr uint32_t kShards = 8;          // tile-ticket counters
 constexpr uint32_t kCtlStart = 0;        // arrival ticket -> virtual workgroup id
 constexpr uint32_t kCtlShard0 = 16;      // shard i at kCtlShard0 + 16*i (own 64-B line)
 constexpr uint32_t kCtlError = 160;      // sticky error bits
+constexpr uint32_t kCtlCensus = 161;     // census mode: workgroups resident together
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
 constexpr uint32_t kErrTimeout = 1u;     // a bounded look-back spin expired
 constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity
@@ -36,7 +37,10 @@ constexpr uint64_t kStatusPrefix = 2ull << kStatusShift;
 constexpr uint64_t kValueMask = (1ull << kStatusShift) - 1;
 
 // ---- compress geometry: one wavefront owns one segment --------------------
-constexpr int kCompressWaves = 8; // segments per tile (workgroup = 512 threads)
+// worker wavefronts = segments per tile: 7 (+1 scan wave = 512 threads, 2 workgroups per CU) or
+// 15 (+1 = 1024 threads, 1 workgroup per CU); WAH_WORKERS selects at run time for experiments
+constexpr int kCompressWavesDefault = 7;
+int compress_workers();
 
 // ---- decode scan geometry -------------------------------------------------
 constexpr int kScanThreads = 256;
@@ -47,16 +51,17 @@ constexpr int kExpandWaves = 4;                                    // segments p
 struct CompressArgs {
     const uint32_t *in;
     uint64_t n_words;
-    uint64_t n_groups;
-    uint64_t n_segments;
-    uint64_t n_tiles;
+    uint32_t n_segments;          // ceil(G / 1024)
+    uint32_t n_tiles;             // ceil(n_segments / kCompressWaves)
+    uint32_t fast_segments;       // segments that lie wholly inside a 16-byte aligned input (prefetch path)
+    uint32_t last_segment_groups; // groups of the last segment (1..1024)
     uint32_t *out;
     uint64_t out_capacity;
     uint64_t *out_words;   // device scalar: C
     uint64_t *seg_offsets; // optional, n_segments + 1 entries
     uint32_t *ctrl;        // kCtlWords
-    uint64_t *desc;        // n_tiles
-    int aligned16;
+    uint32_t *gen_desc;    // generation rows: one 4-byte granule per tile (see resolve_generation)
+    int census;            // 1: residency census only (see compress_grid)
 };
 
 struct ScanArgs {
@@ -69,6 +74,7 @@ struct ScanArgs {
     uint64_t seg_capacity;
     uint32_t *ctrl;
     uint64_t *desc;
+    uint64_t *block_desc;
     int aligned16;
 };
 
@@ -85,8 +91,8 @@ struct ExpandArgs {
 };
 
 // launchers (wah_kernels.hip)
-hipError_t launch_compress(const CompressArgs &a, int grid, hipStream_t s);
-int compress_grid(uint64_t n_tiles);
+hipError_t launch_compress(int workers, const CompressArgs &a, int grid, hipStream_t s);
+int compress_grid(int workers, uint32_t *d_ctrl, hipStream_t s);
 hipError_t launch_decode_scan(const ScanArgs &a, int grid, hipStream_t s);
 int decode_scan_grid(uint64_t n_tiles);
 hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t max_segments, hipStream_t s);

@@ -32,6 +32,27 @@ namespace {
 using u32 = uint32_t;
 using u64 = uint64_t;
 
+// Diagnostic build only (make diag): per-phase cycle totals of each workgroup's thread 0, added into the unused
+// tail of the control block.  The product build contains no stamps.
+#ifdef WAH_DIAG
+#define WAH_STAMP_DECL u64 dg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 dg_prev = __builtin_readcyclecounter();
+#define WAH_STAMP(i)                                      \
+    do {                                                  \
+        const u64 dg_now = __builtin_readcyclecounter();  \
+        dg_acc[i] += dg_now - dg_prev;                    \
+        dg_prev = dg_now;                                 \
+    } while (0)
+#define WAH_STAMP_FLUSH(ctrl)                                                                      \
+    do {                                                                                           \
+        if (threadIdx.x == 0)                                                                      \
+            for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 192) + i, (unsigned long long)dg_acc[i]); \
+    } while (0)
+#else
+#define WAH_STAMP_DECL
+#define WAH_STAMP(i)
+#define WAH_STAMP_FLUSH(ctrl)
+#endif
+
 constexpr u32 kSegLdsWords = 1008;  // 992 + 1 look-ahead word, padded to a multiple of 16 bytes
 constexpr u32 kMaxSpins = 1u << 21; // bounded look-back wait
 
@@ -68,6 +89,13 @@ __device__ __forceinline__ u64 wave_scan_incl(u64 v, u32 lane) {
     return v;
 }
 
+// Values read back from LDS are wave-uniform here by construction; readfirstlane tells the compiler so, which
+// keeps everything derived from them (segment numbers, masks, offsets, branches) on the scalar unit.
+__device__ __forceinline__ u32 uniform32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uniform64(u64 v) {
+    return ((u64)uniform32((u32)(v >> 32)) << 32) | uniform32((u32)v);
+}
+
 // Number of set bits of a wave-uniform mask below this lane (v_mbcnt pair).
 __device__ __forceinline__ u32 rank_below(u64 m) {
     return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
@@ -85,220 +113,459 @@ __device__ __forceinline__ u32 rank_below(u64 m) {
 __device__ __forceinline__ u32 draw_arrival(u32 *ctrl) {
     return __hip_atomic_fetch_add(ctrl + kCtlStart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ u64 draw_tile(u32 *ctrl, u32 shard) {
+// (tile numbers are 32-bit: hosts reject inputs with 2^31 tiles or more; a shard counter that runs past the
+//  end only ever yields numbers >= n_tiles because every workgroup stops at its first such ticket)
+__device__ __forceinline__ u32 draw_tile(u32 *ctrl, u32 shard) {
     const u32 j = __hip_atomic_fetch_add(ctrl + kCtlShard0 + 16u * shard, 1u, __ATOMIC_RELAXED,
                                          __HIP_MEMORY_SCOPE_AGENT);
-    return (u64)j * kShards + shard;
+    return j * kShards + shard;
 }
 
 // ---------------------------------------------------------------------------
-// Decoupled look-back, executed by one full wavefront.  Lane i inspects the
-// descriptor of tile (idx - i): 64 predecessors per poll.  Returns the sum of
-// the aggregates of all tiles < `tile`.  Descriptors are single 8-byte
-// granules, so no fence is needed: the data IS the flag.
+// Two-level decoupled look-back, executed by one full wavefront in ONE round trip.
+//
+// A flat look-back advances its "prefix frontier" by one window (64 tiles) per poll round trip, which caps the
+// whole kernel at window * tile_bytes / poll_latency (measured: the look-back was 45 % of a tile's lifetime).
+// Here tiles are grouped into blocks of 32:
+//   tile  descriptor t : {AGGREGATE, words of tile t}                     -- one store per tile
+//   block descriptor b : {AGGREGATE, words of block b} then {PREFIX, words of blocks 0..b}
+// One 64-lane poll reads, side by side,
+//   lanes  0..31 : the earlier tiles of my own block          (all must be published)
+//   lanes 32..63 : the 32 blocks in front of mine             (up to the nearest PREFIX)
+// so the frontier moves 32 blocks = 1024 tiles per round trip, and a tile needs no PREFIX status at all.
+// The block descriptors are written by the block's LAST tile (index 31), which sees every tile aggregate of the
+// block in its own poll anyway -- no atomics.  Descriptors are single 8-byte granules written and read with
+// agent-scope relaxed atomics (sc1): the data IS the flag, correct across the 8 non-coherent XCD L2s.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ u64 lookback_exclusive(const u64 *desc, u64 tile, u32 lane, u32 *ctrl) {
-    u64 acc = 0;
-    long long idx = (long long)tile - 1;
+constexpr u32 kBlockTiles = 32;
+
+__device__ __forceinline__ u64 resolve_tile_prefix(u64 *tile_desc, u64 *block_desc, u64 tile, u64 aggregate, u32 lane,
+                                                   u32 *ctrl) {
+    const u64 blk = tile / kBlockTiles;
+    const u32 j = (u32)(tile % kBlockTiles);
+    if (lane == 0) desc_store(tile_desc + tile, kStatusAggregate | aggregate);
+
+    const bool tile_lane = lane < 32;
+    const u32 k = lane - 32; // block lanes: distance (in blocks) behind the newest block of the window
+    bool have_intra = (j == 0), have_blocks = (blk == 0);
+    bool block_aggregate_published = false;
+    u64 intra = 0, before = 0;
+    long long newest = (long long)blk - 1; // newest block of the current block-level window
     u32 spins = 0;
-    for (;;) {
-        const long long mine = idx - (long long)lane;
-        u64 d = kStatusPrefix; // virtual "prefix 0" in front of tile 0
-        if (mine >= 0) d = desc_load(desc + mine);
+
+    while (!(have_intra && have_blocks)) {
+        u64 d = 0;
+        if (tile_lane) {
+            if (!have_intra && lane < j) d = desc_load(tile_desc + blk * kBlockTiles + lane);
+        } else if (!have_blocks) {
+            const long long bb = newest - (long long)k;
+            d = bb >= 0 ? desc_load(block_desc + bb) : kStatusPrefix; // virtual "prefix 0" in front of block 0
+        }
         const u32 st = (u32)(d >> kStatusShift);
-        const u64 invalid = __ballot(st == 0u);
-        const u64 prefix = __ballot(st == 2u);
-        if (prefix) {
-            const u32 first = (u32)__ffsll((long long)prefix) - 1u; // nearest predecessor with a full prefix
-            const u64 nearer = (1ull << first) - 1ull;
-            if ((invalid & nearer) == 0) {
-                acc += wave_sum(lane <= first ? (d & kValueMask) : 0ull);
-                return acc;
+        const u64 val = d & kValueMask;
+        bool progressed = false;
+
+        if (!have_intra) {
+            const u64 missing = __ballot(tile_lane && lane < j && st == 0u);
+            if (missing == 0) {
+                intra = uniform64(wave_sum((tile_lane && lane < j) ? val : 0ull));
+                have_intra = true;
+                progressed = true;
             }
-        } else if (invalid == 0) {
-            acc += wave_sum(d & kValueMask);
-            idx -= 64;
+        }
+        // the block's last tile knows the block aggregate as soon as its intra-block poll is complete:
+        // publish it at once so later blocks never wait for this tile's own block-level resolution
+        if (have_intra && j == kBlockTiles - 1 && !block_aggregate_published) {
+            if (lane == 0) desc_store(block_desc + blk, kStatusAggregate | (intra + aggregate));
+            block_aggregate_published = true;
+        }
+        if (!have_blocks) {
+            const u32 invalid = (u32)(__ballot(!tile_lane && st == 0u) >> 32);
+            const u32 prefix = (u32)(__ballot(!tile_lane && st == 2u) >> 32);
+            if (prefix) {
+                const u32 first = (u32)__ffs((int)prefix) - 1u; // nearest block with a full prefix
+                if ((invalid & ((1u << first) - 1u)) == 0) {
+                    before += uniform64(wave_sum((!tile_lane && k <= first) ? val : 0ull));
+                    have_blocks = true;
+                    progressed = true;
+                }
+            } else if (invalid == 0) { // 32 block aggregates and no prefix yet: keep walking back
+                before += uniform64(wave_sum(!tile_lane ? val : 0ull));
+                newest -= 32;
+                progressed = true;
+            }
+        }
+        if (!progressed) {
+            if (++spins > kMaxSpins) {
+                if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        } else {
             spins = 0;
-            continue;
         }
-        if (++spins > kMaxSpins) {
-            if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
-            return acc;
-        }
-        __builtin_amdgcn_s_sleep(1);
     }
+    const u64 excl = before + intra;
+    if (j == kBlockTiles - 1 && lane == 0) desc_store(block_desc + blk, kStatusPrefix | (excl + aggregate));
+    return excl;
 }
 
-// Publish this tile's aggregate, resolve its exclusive prefix, publish the
-// inclusive prefix.  Whole wavefront; returns the exclusive prefix.
-__device__ __forceinline__ u64 tile_prefix(u64 *desc, u64 tile, u64 aggregate, u32 lane, u32 *ctrl) {
-    u64 excl = 0;
-    if (tile == 0) {
-        if (lane == 0) desc_store(desc, kStatusPrefix | aggregate);
-    } else {
-        if (lane == 0) desc_store(desc + tile, kStatusAggregate | aggregate);
-        excl = lookback_exclusive(desc, tile, lane, ctrl);
-        if (lane == 0) desc_store(desc + tile, kStatusPrefix | (excl + aggregate));
+// ---------------------------------------------------------------------------
+// Generation scan: the one-hop offset resolution of the persistent compress kernel.
+//
+// With the static round robin (tile = slot + generation * G) the G tiles of a generation are in flight together,
+// so a chained look-back needs several store->poll hops per generation and every workgroup stalls for all of them.
+// Here each tile publishes ONE 4-byte granule {valid, words} in its generation's row, and reads
+//     row[gen][0 .. slot)     -> words in front of it inside its generation            (poll until all valid)
+//     row[gen-1](slot .. G)   -> the rest of the previous generation's total          (normally valid already)
+// Every workgroup carries the running total of all earlier generations in registers (GenScan), so there is no
+// prefix descriptor, no chain and exactly one hop: publish, poll once, done.  Granules are naturally aligned
+// 4-byte words written and read with agent-scope relaxed atomics (sc1), the data is the flag.
+// ---------------------------------------------------------------------------
+constexpr u32 kGenValid = 0x80000000u;
+
+struct GenScan {
+    u64 gen_base;   // words of all generations before the current one
+    u32 below_prev; // previous generation: words of slots below mine
+    u32 own_prev;   // previous generation: my own words
+};
+
+__device__ __forceinline__ void publish_generation(u32 *gdesc, u32 gen, u32 slot, u32 row_stride, u32 aggregate) {
+    __hip_atomic_store(gdesc + (u64)gen * row_stride + slot, kGenValid | aggregate, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Whole wavefront.  Returns the number of words in front of tile (gen, slot); `aggregate` is that tile's own count
+// (already published).
+__device__ __forceinline__ u64 resolve_generation(const u32 *gdesc, u32 gen, u32 slot, u32 G, u32 row_stride,
+                                                  u32 aggregate, GenScan &st, u32 lane, u32 *ctrl) {
+    const u32 *cur = gdesc + (u64)gen * row_stride;
+    const u32 *prv = cur - row_stride; // only dereferenced when gen > 0
+
+    bool need_prev = gen > 0 && slot + 1 < G, need_cur = slot > 0;
+    u32 above = 0, below = 0, spins = 0;
+    while (need_prev || need_cur) {
+        u32 sum_cur = 0, sum_prev = 0;
+        bool bad_cur = false, bad_prev = false;
+        // lane l looks at entries 2l, 2l+1 (+128 per trip) as one 8-byte load per row
+        for (u32 k0 = 2u * lane; k0 < G; k0 += 128u) {
+            if (need_cur && k0 < slot) {
+                const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(cur + k0), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+                const u32 e0 = (u32)v, e1 = (u32)(v >> 32);
+                bad_cur |= !(e0 & kGenValid);
+                sum_cur += e0 & ~kGenValid;
+                if (k0 + 1 < slot) {
+                    bad_cur |= !(e1 & kGenValid);
+                    sum_cur += e1 & ~kGenValid;
+                }
+            }
+            if (need_prev && k0 + 1 > slot) {
+                const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(prv + k0), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+                const u32 e0 = (u32)v, e1 = (u32)(v >> 32);
+                if (k0 > slot) {
+                    bad_prev |= !(e0 & kGenValid);
+                    sum_prev += e0 & ~kGenValid;
+                }
+                if (k0 + 1 < G) {
+                    bad_prev |= !(e1 & kGenValid);
+                    sum_prev += e1 & ~kGenValid;
+                }
+            }
+        }
+        bool progressed = false;
+        if (need_cur && !__any(bad_cur)) {
+            below = uniform32(wave_sum32(sum_cur));
+            need_cur = false;
+            progressed = true;
+        }
+        if (need_prev && !__any(bad_prev)) {
+            above = uniform32(wave_sum32(sum_prev));
+            need_prev = false;
+            progressed = true;
+        }
+        if (!progressed) {
+            if (++spins > kMaxSpins) {
+                if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
     }
-    return excl;
+    if (gen > 0) st.gen_base += (u64)st.below_prev + st.own_prev + above;
+    st.below_prev = below;
+    st.own_prev = aggregate;
+    return st.gen_base + below;
 }
 
 // ===========================================================================
 // compress
+//
+// Workgroup = W worker wavefronts + 1 scan wavefront, persistent, ONE barrier per iteration.
+//   worker w : owns segment tile*W + w.  Per iteration g: the 4 x 16-byte loads of its segment were issued an
+//              iteration earlier (software prefetch); it stages them in one of its two private 4 KiB LDS buffers,
+//              issues the next tile's loads, classifies, compacts the run-end words in place, turns them into
+//              final WAH words (fill length = distance between consecutive run ends) -- none of which needs the
+//              output offset -- and leaves them in LDS.  After the barrier it streams out the PREVIOUS tile's
+//              words (other buffer) with dense 256-byte stores at the offset resolved meanwhile.
+//   scan wave: never touches bitmap data, so its memory queue only holds granule traffic.  After the barrier it
+//              publishes the tile's word count; during the workers' next classify it resolves the offset.
+// Resolution of tile g thus overlaps classification of tile g+1: a workgroup only stalls when a predecessor is a
+// whole iteration late, instead of every generation waiting for its slowest member.
 // ===========================================================================
+constexpr u32 kStageWords = 1024; // staged segment (992 words + look-ahead) / compacted output words (<= 1024), aliased
+constexpr u32 kPosEntries = 1032; // pos[0] = -1 sentinel, pos[k+1] = group position of run end k (u16)
 
-// Stage one segment (992 words, zero padded past the end of the input) in LDS.
-__device__ __forceinline__ void stage_segment(const CompressArgs &a, u64 seg, u32 *lds, u32 lane) {
-    const u64 w0 = seg * kSegWords;
-    if (a.aligned16 && w0 + kSegWords <= a.n_words) {
-        // 3968 B = 248 x 16 B: four coalesced dwordx4 loads per lane, issued back to back
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.in + w0);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds);
-        const uint4 v0 = src[lane];
-        const uint4 v1 = src[lane + 64];
-        const uint4 v2 = src[lane + 128];
-        uint4 v3 = make_uint4(0, 0, 0, 0);
-        if (lane < 56) v3 = src[lane + 192];
-        dst[lane] = v0;
-        dst[lane + 64] = v1;
-        dst[lane + 128] = v2;
-        if (lane < 56) dst[lane + 192] = v3;
-    } else {
-        for (u32 i = lane; i < kSegWords; i += 64) lds[i] = (w0 + i < a.n_words) ? a.in[w0 + i] : 0u;
-    }
-    if (lane == 0) lds[kSegWords] = 0u; // look-ahead word of the last group (masked out by the 31-bit mask)
-    // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+struct Prefetch {
+    uint4 v[4];
+};
+
+// issue the four coalesced 16-byte loads of one whole segment (3968 B = 248 x 16 B)
+__device__ __forceinline__ void prefetch_segment(const u32 *in, u32 seg, u32 lane, Prefetch &p) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + (u64)seg * kSegWords);
+    p.v[0] = src[lane];
+    p.v[1] = src[lane + 64];
+    p.v[2] = src[lane + 128];
+    p.v[3] = src[lane < 56 ? lane + 192 : 247];
 }
 
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64, 8) void compress_kernel(const CompressArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 s_seg[WAVES][kSegLdsWords];
-    __shared__ u32 s_count[WAVES];
-    __shared__ u64 s_tile;
-    __shared__ u64 s_base;
+__device__ __forceinline__ void stage_prefetched(const Prefetch &p, u32 *lds, u32 lane) {
+    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    dst[lane] = p.v[0];
+    dst[lane + 64] = p.v[1];
+    dst[lane + 128] = p.v[2];
+    if (lane < 56) dst[lane + 192] = p.v[3];
+    if (lane == 0) lds[kSegWords] = 0u; // look-ahead word of the last group (masked out by the 31-bit mask)
+}
+
+// tail segment or 4-byte aligned input: bounds-checked scalar staging, zero padded (F5)
+__device__ __forceinline__ void stage_slow(const CompressArgs &a, u32 seg, u32 *lds, u32 lane) {
+    const u64 w0 = (u64)seg * kSegWords;
+    const u64 left = a.n_words - w0;
+    const u32 have = left < kSegWords ? (u32)left : kSegWords; // wave-uniform
+    const u32 *src = a.in + w0;
+    for (u32 i = lane; i < kSegWords + 64; i += 64)
+        if (i <= kSegWords) lds[i] = i < have ? src[i] : 0u;
+}
+
+// Classify + run detect + compact one staged segment (wave-private LDS), returns the number of words produced.
+//   classify  (kernels.cu:93-112): group = funnel shift of two staged words; zero / ones kinds by v_cmp, whose
+//             result IS the 64-lane mask.
+//   run ends  (kernels.cu:126-141 + the cross-warp merge of :188-229): a group does NOT end a run iff it is a
+//             fill and the next group of the segment has the same value.  "Same as next" is one DPP compare
+//             against the neighbouring lane (lane 63 is patched with lane 0 of the following step), so the
+//             scalar side is three mask operations per 64 groups.  The group after the last one never matches,
+//             so every segment closes its last run (tests.cpp:166-172).
+//   compact   : step s-1 is finished once step s is classified; its run-end words go to LDS at rank = running
+//             count + mbcnt, written over staged words that every later step has already left behind
+//             (rank < 64 s <= 62 (s+1), the lowest word still to be read), with the group position beside it
+//             (fill lengths are position differences, see the emit loop).
+// kFull = all 1024 groups exist (every segment but possibly the last one of the bitmap).
+template <bool kFull>
+__device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigned short *pos, u32 r, u32 lane_v,
+                                                u32 nvalid) {
+    u32 count = 0;
+    u32 xprev = 0;
+    u64 fprev = 0, vprev = 0;
+#pragma unroll
+    for (int s = 0; s <= (int)kSteps; ++s) {
+        u32 xv = 0xFFFFFFFFu; // flush step: a value no 31-bit group can equal
+        u64 fill = 0, valid = 0;
+        if (s < (int)kSteps) {
+            const u32 lo = sp[62 * s];
+            const u32 hi = sp[62 * s + 1];
+            xv = __builtin_amdgcn_alignbit(hi, lo, r) & kOnes31;
+            fill = __ballot(xv == 0u) | __ballot(xv == kOnes31);
+            if (kFull) {
+                valid = ~0ull;
+            } else {
+                const int rem = (int)nvalid - 64 * s;
+                valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+                fill &= valid;
+            }
+        }
+        if (s > 0) {
+            // lane l: value of the next group = xprev of lane l+1; lane 63: first group of step s
+            // (a lane without a source -- lane 63 -- keeps the `old` operand of the DPP move)
+            const u32 first_of_next = (u32)__builtin_amdgcn_readfirstlane((int)xv);
+            const u32 nxt = __builtin_amdgcn_update_dpp(first_of_next, xprev, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            u64 same = __ballot(nxt == xprev);
+            if (!kFull) same &= (valid << 63) | (vprev >> 1); // the successor must exist
+            const u64 e = vprev & ~(fprev & same);
+            if (e) {
+                if (__builtin_amdgcn_inverse_ballot_w64(e)) {
+                    const u32 rank = count + rank_below(e);
+                    lds[rank] = xprev;
+                    pos[rank + 1] = (unsigned short)(64 * (s - 1) + (int)lane_v);
+                }
+                count += (u32)__popcll(e);
+            }
+        }
+        xprev = xv;
+        fprev = fill;
+        vprev = valid;
+    }
+    return count;
+}
+
+// Tile assignment is a static round robin over the workgroups in ARRIVAL order: the workgroup that draws arrival
+// ticket v processes tiles v, v + G, v + 2G, ... (G = grid size).  Every generation of G consecutive tiles is
+// then in flight at once and no workgroup ever holds a tile that sits below a tile somebody else is already
+// waiting behind (dynamic tickets drawn ahead of time do exactly that, and serialise the scan).  It needs all
+// G workgroups to be resident together: the host sizes G from a residency census of this very kernel
+// (census mode below), and every wait is bounded, so a lost workgroup ends in WAH_ERR_TIMEOUT, never in a hang.
+template <int W>
+__global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 s_out[2][W][kStageWords];
+    __shared__ unsigned short s_pos[W][kPosEntries];
+    __shared__ u32 s_count[3][W];
+    __shared__ u32 s_arrival;
+    __shared__ u64 s_base[2];
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
-    const u64 lt = (1ull << lane) - 1ull; // lanes below me
+    const bool worker = wave < (u32)W;
 
-    // regroup constants: group g = 64*step + lane starts at stream bit 31*g;
-    // 64 groups = 1984 bits = 62 words exactly, so the in-word shift is fixed per lane
-    const u32 q0 = (31u * lane) >> 5;
+    if (threadIdx.x == 0) s_arrival = draw_arrival(a.ctrl);
+    __syncthreads();
+    const u32 arrival = uniform32(s_arrival);
+
+    if (a.census) {
+        // residency census: how many workgroups of this kernel are running together?  Everybody that is resident
+        // arrives within about a microsecond; whoever is not cannot start before a resident one exits.
+        if (threadIdx.x == 0) {
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 3000) __builtin_amdgcn_s_sleep(8); // 30 us (100 MHz)
+            if (arrival == 0)
+                a.ctrl[kCtlCensus] = __hip_atomic_load(a.ctrl + kCtlStart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+
+    // regroup constants: group g = 64*step + lane starts at stream bit 31*g; 64 groups = 1984 bits = 62 words
+    // exactly, so the in-word shift is fixed per lane and the word index advances by 62 per step
     const u32 r = (31u * lane) & 31u;
+    const u32 stride = gridDim.x;
+    const u32 row_stride = (stride + 3u) & ~3u;
+    const u32 ww = worker ? wave : 0;
+    unsigned short *const pos = s_pos[ww];
 
-    if (threadIdx.x == 0) s_tile = draw_arrival(a.ctrl);
-    __syncthreads();
-    const u32 shard = (u32)s_tile % kShards;
-    __syncthreads();
+    Prefetch pre;
+    pre.v[0] = pre.v[1] = pre.v[2] = pre.v[3] = make_uint4(0, 0, 0, 0);
+    bool pre_valid = false; // wave-uniform: `pre` holds the current tile's segment
+    {
+        const u32 seg = arrival * W + wave;
+        if (worker && arrival < a.n_tiles && seg < a.fast_segments) {
+            prefetch_segment(a.in, seg, lane, pre);
+            pre_valid = true;
+        }
+    }
 
-    for (;;) {
-        if (threadIdx.x == 0) s_tile = draw_tile(a.ctrl, shard);
-        __syncthreads();
-        const u64 tile = s_tile;
-        if (tile >= a.n_tiles) break;
-
-        const u64 seg = tile * WAVES + wave;
-        u32 x[kSteps];
-        u64 ends[kSteps];
+    GenScan scan = {0, 0, 0};
+    u32 prev_aggregate = 0; // scan wave: words of the previous tile (published, not yet resolved)
+    u32 prev_count = 0;     // worker: words of its previous segment (in LDS, not yet written out)
+    WAH_STAMP_DECL
+    u32 gen = 0, par = 0, slot3 = 0, prev_slot3 = 0;
+    for (u32 tile = arrival;; tile += stride, ++gen, par ^= 1u) {
+        const bool has_cur = tile < a.n_tiles;
+        const bool has_prev = gen > 0;
+        const u32 seg = tile * W + wave; // workers only
+        u32 *const lds = s_out[par][ww];
         u32 count = 0;
+        // Opaque copy of the lane id, renewed every iteration: per-step constants derived from it (group
+        // positions, LDS addresses) are then recomputed next to their use instead of being hoisted out of the
+        // persistent loop, where 16 + 16 of them would be kept live and spilled.
+        u32 lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
 
-        if (seg < a.n_segments) {
-            u32 *lds = s_seg[wave];
-            stage_segment(a, seg, lds, lane);
-
-            const u64 g0 = seg * kSegGroups;
-            const u32 nvalid = (a.n_groups - g0 < kSegGroups) ? (u32)(a.n_groups - g0) : kSegGroups;
-
-            // classify (kernels.cu:93-112): one v_cmp per kind gives the 64-lane mask directly.
-            // run ends (kernels.cu:126-141 + the merge of :188-229): a group does NOT end a run iff it
-            // and its successor inside the segment are the same kind of fill.  The successor masks of
-            // the last valid group are zero, so every segment closes its last run (tests.cpp:166-172).
-            // Step s-1 is finished as soon as step s has been classified (needs its bit 0 only).
-            const u32 *sp = lds + q0;
-            u64 zprev = 0, oprev = 0, vprev = 0;
-#pragma unroll
-            for (int s = 0; s < (int)kSteps; ++s) {
-                const u32 lo = sp[62 * s];
-                const u32 hi = sp[62 * s + 1];
-                const u32 xv = __builtin_amdgcn_alignbit(hi, lo, r) & kOnes31;
-                x[s] = xv;
-                const int rem = (int)nvalid - 64 * s;
-                const u64 valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-                const u64 z = __ballot(xv == 0u) & valid;
-                const u64 o = __ballot(xv == kOnes31) & valid;
-                if (s > 0) {
-                    const u64 zn = (zprev >> 1) | (z << 63);
-                    const u64 on = (oprev >> 1) | (o << 63);
-                    ends[s - 1] = vprev & ~((zprev & zn) | (oprev & on));
-                    count += (u32)__popcll(ends[s - 1]);
+        if (worker) {
+            if (has_cur) {
+                if (seg < a.n_segments) {
+                    if (pre_valid)
+                        stage_prefetched(pre, lds, lane);
+                    else
+                        stage_slow(a, seg, lds, lane);
                 }
-                zprev = z;
-                oprev = o;
-                vprev = valid;
-            }
-            ends[kSteps - 1] = vprev & ~((zprev & (zprev >> 1)) | (oprev & (oprev >> 1)));
-            count += (u32)__popcll(ends[kSteps - 1]);
-        } else {
-#pragma unroll
-            for (int s = 0; s < (int)kSteps; ++s) {
-                x[s] = 0;
-                ends[s] = 0;
-            }
-        }
+                // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                WAH_STAMP(0);
 
-        if (lane == 0) s_count[wave] = count;
-        __syncthreads();
-
-        // one wavefront resolves the tile's output offset (replaces compress.cu:133-157)
-        if (wave == 0) {
-            const u32 mine = lane < (u32)WAVES ? s_count[lane] : 0u;
-            const u64 aggregate = wave_sum32(mine);
-            const u64 excl = tile_prefix(a.desc, tile, aggregate, lane, a.ctrl);
-            if (lane == 0) {
-                s_base = excl;
-                if (tile == a.n_tiles - 1) {
-                    *a.out_words = excl + aggregate;
-                    if (a.seg_offsets) a.seg_offsets[a.n_segments] = excl + aggregate;
+                // software prefetch of the next tile's segment: in flight during everything below
+                {
+                    const u32 next_tile = tile + stride;
+                    const u32 nseg = next_tile * W + wave;
+                    pre_valid = next_tile < a.n_tiles && nseg < a.fast_segments;
+                    if (pre_valid) prefetch_segment(a.in, nseg, lane, pre);
                 }
-                if (excl + aggregate > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
-            }
-        }
-        __syncthreads();
 
-        u64 base = s_base;
-        for (u32 w = 0; w < wave; ++w) base += s_count[w];
-        const bool fits = base + count <= a.out_capacity;
-
-        if (seg < a.n_segments) {
-            if (lane == 0 && a.seg_offsets) a.seg_offsets[seg] = base;
-            if (fits) {
-                // emit (kernels.cu:233-259): rank by mbcnt, run length = distance to the previous run end
-                u32 *dst = a.out + base;
-                u32 done = 0;
-                int last_end = -1;
-#pragma unroll
-                for (int s = 0; s < (int)kSteps; ++s) {
-                    const u64 e = ends[s];
-                    if (e) {
-                        const u32 xv = x[s];
-                        const bool isz = xv == 0u, iso = xv == kOnes31;
-                        const u64 below = e & lt;
-                        u32 val = xv;
-                        if (__ballot(isz || iso) & e) {
-                            const int prev = below ? (64 * s + 63 - (int)__clzll((long long)below)) : last_end;
-                            const u32 len = (u32)(64 * s + (int)lane - prev);
-                            val = isz ? (kFillZero | len) : (iso ? (kFillOne | len) : xv);
-                        }
-                        if ((e >> lane) & 1ull) dst[done + rank_below(e)] = val;
-                        done += (u32)__popcll(e);
-                        last_end = 64 * s + 63 - (int)__clzll((long long)e);
+                if (seg < a.n_segments) {
+                    const u32 nvalid = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
+                    if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
+                    const u32 *sp = lds + ((31u * lane_v) >> 5);
+                    count = nvalid == kSegGroups ? classify_compact<true>(sp, lds, pos, r, lane_v, nvalid)
+                                                 : classify_compact<false>(sp, lds, pos, r, lane_v, nvalid);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    // final words in place (kernels.cu:244-249): fill length = distance between consecutive run ends
+                    for (u32 j = lane; j < count; j += 64) {
+                        const u32 v = lds[j];
+                        const u32 len = ((u32)pos[j + 1] - (u32)pos[j]) & 0xFFFFu;
+                        lds[j] = v == 0u ? (kFillZero | len) : (v == kOnes31 ? (kFillOne | len) : v);
                     }
                 }
+                WAH_STAMP(1);
+                if (lane == 0) s_count[slot3][wave] = count;
+            }
+        } else if (has_prev) {
+            // scan wave: resolve the previous tile's output offset while the workers classify this one
+            // (replaces the scan + read-backs of compress.cu:133-157)
+            const u32 ptile = tile - stride;
+            const u64 excl = resolve_generation(a.gen_desc, gen - 1, arrival, stride, row_stride, prev_aggregate, scan,
+                                                lane, a.ctrl);
+            if (lane == 0) {
+                s_base[par ^ 1u] = excl;
+                if (ptile == a.n_tiles - 1) {
+                    *a.out_words = excl + prev_aggregate;
+                    if (a.seg_offsets) a.seg_offsets[a.n_segments] = excl + prev_aggregate;
+                }
+                if (excl + prev_aggregate > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
             }
         }
-        // s_tile / s_count / s_base are rewritten only after the next iteration's first barrier
+        __syncthreads();
+        WAH_STAMP(2);
+
+        if (!worker) {
+            if (has_cur) {
+                const u32 mine = lane < (u32)W ? s_count[slot3][lane] : 0u;
+                prev_aggregate = uniform32(wave_sum32(mine));
+                if (lane == 0) publish_generation(a.gen_desc, gen, arrival, row_stride, prev_aggregate);
+            }
+        } else if (has_prev) {
+            // stream out the previous tile's words (kernels.cu:256 + moveData, kernels.cu:273-280)
+            const u32 pseg = (tile - stride) * W + wave;
+            if (pseg < a.n_segments) {
+                u64 base = uniform64(s_base[par ^ 1u]);
+                for (u32 w = 0; w < wave; ++w) base += uniform32(s_count[prev_slot3][w]);
+                if (lane == 0 && a.seg_offsets) a.seg_offsets[pseg] = base;
+                if (base + prev_count <= a.out_capacity) {
+                    const u32 *src = s_out[par ^ 1u][ww];
+                    u32 *dst = a.out + base;
+                    for (u32 j = lane; j < prev_count; j += 64) dst[j] = src[j];
+                }
+            }
+            // the iteration after next restages this buffer: order these reads before those writes
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        WAH_STAMP(3);
+        if (!has_cur) break;
+        prev_count = count;
+        prev_slot3 = slot3;
+        slot3 = slot3 == 2 ? 0 : slot3 + 1;
+#ifdef WAH_DIAG
+        dg_acc[7] += 1;
+#endif
     }
+    WAH_STAMP_FLUSH(a.ctrl);
 }
 
 // ===========================================================================
@@ -358,7 +625,7 @@ __global__ __launch_bounds__(kScanThreads) void decode_scan_kernel(const ScanArg
         if (wave == 0) {
             const u64 ws = lane < kScanThreads / 64 ? s_wave_sum[lane] : 0ull;
             const u64 aggregate = wave_sum(ws);
-            const u64 excl = tile_prefix(a.desc, tile, aggregate, lane, a.ctrl);
+            const u64 excl = resolve_tile_prefix(a.desc, a.block_desc, tile, aggregate, lane, a.ctrl);
             if (lane == 0) {
                 s_base = excl;
                 if (tile == a.n_tiles - 1) {
@@ -516,12 +783,43 @@ int persistent_grid(const void *kernel, int threads, u64 n_tiles) {
 
 } // namespace
 
-int compress_grid(u64 n_tiles) {
-    return persistent_grid(reinterpret_cast<const void *>(&compress_kernel<kCompressWaves>), kCompressWaves * 64, n_tiles);
+// Grid of the persistent compress kernel = how many of its workgroups are resident together, measured once per
+// device by a census launch of the same kernel (the occupancy API is advisory: MI355X_MICROARCH residency notes).
+template <int W>
+int compress_grid_for(u32 *d_ctrl, hipStream_t s) {
+    static int cached[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] > 0) return cached[dev];
+    const int upper = persistent_grid(reinterpret_cast<const void *>(&compress_kernel<W>), (W + 1) * 64, ~0ull);
+    CompressArgs a = {};
+    a.ctrl = d_ctrl;
+    a.census = 1;
+    int resident = 0;
+    if (hipMemsetAsync(d_ctrl, 0, kCtlWords * sizeof(u32), s) == hipSuccess) {
+        hipLaunchKernelGGL(compress_kernel<W>, dim3(upper), dim3((W + 1) * 64), 0, s, a);
+        u32 seen = 0;
+        if (hipGetLastError() == hipSuccess &&
+            hipMemcpyAsync(&seen, d_ctrl + kCtlCensus, sizeof seen, hipMemcpyDeviceToHost, s) == hipSuccess &&
+            hipStreamSynchronize(s) == hipSuccess)
+            resident = (int)seen;
+    }
+    if (resident < 1) return -1;
+    if (resident > upper) resident = upper;
+    cached[dev] = resident;
+    return resident;
 }
 
-hipError_t launch_compress(const CompressArgs &a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(compress_kernel<kCompressWaves>, dim3(grid), dim3(kCompressWaves * 64), 0, s, a);
+int compress_grid(int workers, u32 *d_ctrl, hipStream_t s) {
+    return workers == 15 ? compress_grid_for<15>(d_ctrl, s) : compress_grid_for<7>(d_ctrl, s);
+}
+
+hipError_t launch_compress(int workers, const CompressArgs &a, int grid, hipStream_t s) {
+    if (workers == 15)
+        hipLaunchKernelGGL(compress_kernel<15>, dim3(grid), dim3(16 * 64), 0, s, a);
+    else
+        hipLaunchKernelGGL(compress_kernel<7>, dim3(grid), dim3(8 * 64), 0, s, a);
     return hipGetLastError();
 }
 

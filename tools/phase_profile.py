@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Per-phase cycle shares of the compress kernel from the DIAGNOSTIC build (make -C gpu-wah_amd diag).
+Reads the stamp totals the kernel added into the control block.  Shares only -- never quote this build's run time."""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["WAH_LIB_PATH"] = os.path.join(ROOT, "gpu-wah_amd", "libwah_hip_diag.so")
+import torch  # noqa: E402
+
+wah = importlib.import_module("gpu-wah_amd")
+names = ["wait loads + stage", "classify+compact", "count barrier", "look-back (scan wave)", "base barrier", "emit", "-", "tiles"]
+n = 268435200
+for kind in sys.argv[1:] or ["sparse", "dense", "clustered"]:
+    d = {"sparse": lambda: wah.gen_uniform_device(n, 1337, 0.01), "dense": lambda: wah.gen_uniform_device(n, 1337, 0.5),
+         "clustered": lambda: wah.gen_clustered_device(n, 1337)}[kind]()
+    comp = wah.DeviceCompressor(n)
+    comp.run(d)
+    comp.status()
+    comp.run(d)
+    comp.status()
+    acc = comp.workspace[768:768 + 128].view(torch.int64).cpu().tolist()
+    tiles = max(acc[7], 1)
+    total = sum(acc[:7])
+    print(f"--- {kind}: {tiles} tiles, {total / tiles:.0f} cycles/tile (thread 0 of each workgroup)")
+    for nm, v in zip(names[:7], acc[:7]):
+        print(f"   {nm:18s} {v / tiles:9.0f} cyc/tile  {100.0 * v / total:5.1f} %")
+    st = max(acc[11], 1)
+    print(f"   scan wave: ticket {acc[8] / st:.0f} cyc, wait-for-workers {acc[9] / st:.0f} cyc, look-back {acc[10] / st:.0f} cyc per tile; "
+          f"poll rounds/tile {acc[12] / st:.2f} (intra pending {acc[13] / st:.2f}, blocks pending {acc[14] / st:.2f})")
+    del comp, d
