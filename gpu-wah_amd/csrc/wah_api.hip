@@ -146,7 +146,7 @@ bool hip_ok(hipError_t e, const char *what) {
 int wah::compress_workers() {
     static const int w = [] {
         const char *e = std::getenv("WAH_WORKERS");
-        return (e && std::atoi(e) == 15) ? 15 : wah::kCompressWavesDefault;
+        return (e && std::atoi(e) == 7) ? 7 : wah::kCompressWavesDefault;
     }();
     return w;
 }

@@ -39,7 +39,7 @@ constexpr uint64_t kValueMask = (1ull << kStatusShift) - 1;
 // ---- compress geometry: one wavefront owns one segment --------------------
 // worker wavefronts = segments per tile: 7 (+1 scan wave = 512 threads, 2 workgroups per CU) or
 // 15 (+1 = 1024 threads, 1 workgroup per CU); WAH_WORKERS selects at run time for experiments
-constexpr int kCompressWavesDefault = 7;
+constexpr int kCompressWavesDefault = 15;
 int compress_workers();
 
 // ---- decode scan geometry -------------------------------------------------

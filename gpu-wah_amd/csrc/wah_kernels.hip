@@ -49,7 +49,7 @@ using u64 = uint64_t;
     } while (0)
 #else
 #define WAH_STAMP_DECL
-#define WAH_STAMP(i)
+#define WAH_STAMP(i) asm volatile("; WAH_MARK " #i ::: "memory")
 #define WAH_STAMP_FLUSH(ctrl)
 #endif
 
@@ -364,48 +364,54 @@ __device__ __forceinline__ void stage_slow(const CompressArgs &a, u32 seg, u32 *
 // kFull = all 1024 groups exist (every segment but possibly the last one of the bitmap).
 template <bool kFull>
 __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigned short *pos, u32 r, u32 lane_v,
-                                                u32 nvalid) {
-    u32 count = 0;
-    u32 xprev = 0;
-    u64 fprev = 0, vprev = 0;
+                                                u32 nvalid, bool &any_fill) {
+    // phase 1: all 16 LDS reads, then the funnel shifts: every staged word is in registers before the first
+    // compacted word overwrites the staging buffer
+    u32 x[kSteps + 1];
 #pragma unroll
-    for (int s = 0; s <= (int)kSteps; ++s) {
-        u32 xv = 0xFFFFFFFFu; // flush step: a value no 31-bit group can equal
-        u64 fill = 0, valid = 0;
-        if (s < (int)kSteps) {
-            const u32 lo = sp[62 * s];
-            const u32 hi = sp[62 * s + 1];
-            xv = __builtin_amdgcn_alignbit(hi, lo, r) & kOnes31;
-            fill = __ballot(xv == 0u) | __ballot(xv == kOnes31);
-            if (kFull) {
-                valid = ~0ull;
-            } else {
-                const int rem = (int)nvalid - 64 * s;
-                valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-                fill &= valid;
-            }
-        }
-        if (s > 0) {
-            // lane l: value of the next group = xprev of lane l+1; lane 63: first group of step s
-            // (a lane without a source -- lane 63 -- keeps the `old` operand of the DPP move)
-            const u32 first_of_next = (u32)__builtin_amdgcn_readfirstlane((int)xv);
-            const u32 nxt = __builtin_amdgcn_update_dpp(first_of_next, xprev, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-            u64 same = __ballot(nxt == xprev);
-            if (!kFull) same &= (valid << 63) | (vprev >> 1); // the successor must exist
-            const u64 e = vprev & ~(fprev & same);
-            if (e) {
-                if (__builtin_amdgcn_inverse_ballot_w64(e)) {
-                    const u32 rank = count + rank_below(e);
-                    lds[rank] = xprev;
-                    pos[rank + 1] = (unsigned short)(64 * (s - 1) + (int)lane_v);
-                }
-                count += (u32)__popcll(e);
-            }
-        }
-        xprev = xv;
-        fprev = fill;
-        vprev = valid;
+    for (int s = 0; s < (int)kSteps; ++s) {
+        const u32 lo = sp[62 * s];
+        const u32 hi = sp[62 * s + 1];
+        x[s] = __builtin_amdgcn_alignbit(hi, lo, r) & kOnes31;
     }
+    x[kSteps] = 0xFFFFFFFFu; // "group after the last one": a value no 31-bit group can equal
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // phase 2: straight-line, one block per step (no data-dependent branches, so the 16 short dependency chains
+    // can be interleaved by the scheduler):
+    //   fill  = 1 v_sub + 1 v_cmp   : x - 1 >= 0x7FFFFFFE (unsigned)  <=>  x is 0 or 0x7FFFFFFF
+    //   same  = DPP move + v_cmp    : value of the next group (lane 63: `old` operand = lane 0 of the next step)
+    //   ends  = ~(fill & same)      : 1 scalar op
+    //   rank  = v_mbcnt pair seeded with the running count (scalar)
+    u32 count = 0;
+    u64 fill_ends = 0;
+#pragma unroll
+    for (int s = 0; s < (int)kSteps; ++s) {
+        u64 fill = __ballot(x[s] - 1u >= 0x7FFFFFFEu);
+        const u32 first_of_next = (u32)__builtin_amdgcn_readfirstlane((int)x[s + 1]);
+        const u32 nxt = __builtin_amdgcn_update_dpp(first_of_next, x[s], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        u64 same = __ballot(nxt == x[s]);
+        u64 e;
+        if (kFull) {
+            e = ~(fill & same);
+        } else {
+            const int rem = (int)nvalid - 64 * s;
+            const u64 valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+            const u64 next_valid = rem - 64 >= 1 ? 1ull : 0ull; // does group 64 (s+1) exist?
+            fill &= valid;
+            same &= (next_valid << 63) | (valid >> 1); // the successor must exist
+            e = valid & ~(fill & same);
+        }
+        fill_ends |= e & fill;
+        if (__builtin_amdgcn_inverse_ballot_w64(e)) {
+            // running count folded into the (scalar) base address: rank*4 + (lds + count), one v_lshl_add each
+            const u32 rank = rank_below(e);
+            (lds + count)[rank] = x[s];
+            (pos + count + 1)[rank] = (unsigned short)(64 * s + (int)lane_v);
+        }
+        count += (u32)__popcll(e);
+    }
+    any_fill = fill_ends != 0;
     return count;
 }
 
@@ -415,18 +421,68 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
 // waiting behind (dynamic tickets drawn ahead of time do exactly that, and serialise the scan).  It needs all
 // G workgroups to be resident together: the host sizes G from a residency census of this very kernel
 // (census mode below), and every wait is bounded, so a lost workgroup ends in WAH_ERR_TIMEOUT, never in a hang.
+// Hand-offs inside the workgroup go through LDS words, not s_barrier: a wave only ever waits for the one thing it
+// needs.  LDS operations of a wave execute in order and the LDS is coherent inside the CU, so "write data, then
+// write flag" / "see flag, then read data" is enough; the waits below only drain the LDS counter (lgkmcnt),
+// never the vector-memory counter -- the prefetched loads stay in flight.
+// (explicit LDS address space + relaxed workgroup atomics: a volatile access through a generic pointer would be
+//  emitted as a FLAT instruction, which counts on the vector-memory counter as well and forces vmcnt(0) waits)
+using lds_u32_ptr = __attribute__((address_space(3))) u32 *;
+using lds_u64_ptr = __attribute__((address_space(3))) u64 *;
+__device__ __forceinline__ u32 lds_ld(const u32 *p) {
+    return __hip_atomic_load((lds_u32_ptr)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ u64 lds_ld64(const u64 *p) {
+    return __hip_atomic_load((lds_u64_ptr)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(u32 *p, u32 v) {
+    __hip_atomic_store((lds_u32_ptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_publish(u32 *flag, u32 value) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_st(flag, value);
+}
+// A waiting wave must not compete with the working ones: the hardware favours the OLDEST wave of a SIMD, and the
+// oldest waves are exactly the ones that finish first and wait (measured: a busy spin made the youngest worker of a
+// SIMD take 1.75x as long as the oldest).  So: lowest priority and long sleeps while waiting.
+__device__ __forceinline__ bool lds_wait(const u32 *flag, u32 value, u32 *ctrl, u32 lane) {
+    if (lds_ld(flag) != value) {
+        __builtin_amdgcn_s_setprio(0);
+        for (u32 spins = 0; lds_ld(flag) != value;) {
+            if (++spins > kMaxSpins) {
+                if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
+                __builtin_amdgcn_s_setprio(1);
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(6);
+        }
+        __builtin_amdgcn_s_setprio(1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return true;
+}
+
 template <int W>
 __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_out[2][W][kStageWords];
     __shared__ unsigned short s_pos[W][kPosEntries];
-    __shared__ u32 s_count[3][W];
+    __shared__ u32 s_count[4][W];    // words per worker of tile (gen & 3)
+    __shared__ u32 s_arrived[4];     // workers that have delivered their count for tile (gen & 3)
+    __shared__ u32 s_total[4];       // words of tile (gen & 3) ...
+    __shared__ u32 s_total_flag[4];  // ... valid when == gen + 1
+    __shared__ u64 s_base[2];        // output offset of tile (gen & 1) ...
+    __shared__ u32 s_base_flag[2];   // ... valid when == gen + 1
     __shared__ u32 s_arrival;
-    __shared__ u64 s_base[2];
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
     const bool worker = wave < (u32)W;
 
+    if (threadIdx.x < 4) {
+        s_arrived[threadIdx.x] = 0;
+        s_total_flag[threadIdx.x] = 0;
+        if (threadIdx.x < 2) s_base_flag[threadIdx.x] = 0;
+    }
     if (threadIdx.x == 0) s_arrival = draw_arrival(a.ctrl);
     __syncthreads();
     const u32 arrival = uniform32(s_arrival);
@@ -443,129 +499,216 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
         return;
     }
 
+    const u32 stride = gridDim.x;
+    const u32 row_stride = (stride + 3u) & ~3u;
+    WAH_STAMP_DECL
+
+    if (worker)
+        __builtin_amdgcn_s_setprio(1);
+    else
+        __builtin_amdgcn_s_setprio(2);
+    if (!worker) {
+        // ---------------- scan wave: resolve output offsets, tile after tile, as the counts come in ------------
+        GenScan scan = {0, 0, 0};
+        u32 gen = 0;
+        for (u32 tile = arrival; tile < a.n_tiles; tile += stride, ++gen) {
+            if (!lds_wait(&s_total_flag[gen & 3u], gen + 1u, a.ctrl, lane)) break;
+            const u32 aggregate = uniform32(lds_ld(&s_total[gen & 3u]));
+            WAH_STAMP(0);
+            const u64 excl = resolve_generation(a.gen_desc, gen, arrival, stride, row_stride, aggregate, scan, lane, a.ctrl);
+            WAH_STAMP(1);
+#ifdef WAH_DIAG
+            if (lane == 0 && a.seg_offsets) {
+                a.seg_offsets[(u64)tile * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+                a.seg_offsets[(u64)tile * 4 + 3] = ((u64)blockIdx.x << 32) | gen;
+            }
+#endif
+            if (lane == 0) {
+                __hip_atomic_store((lds_u64_ptr)&s_base[gen & 1u], excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_publish(&s_base_flag[gen & 1u], gen + 1u);
+                if (tile == a.n_tiles - 1) {
+                    *a.out_words = excl + aggregate;
+#ifndef WAH_DIAG
+                    if (a.seg_offsets) a.seg_offsets[a.n_segments] = excl + aggregate;
+#endif
+                }
+                if (excl + aggregate > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+            }
+#ifdef WAH_DIAG
+            dg_acc[7] += 1;
+#endif
+        }
+#ifdef WAH_DIAG
+        if (lane == 0)
+            for (int i = 0; i < 2; ++i)
+                atomicAdd(reinterpret_cast<unsigned long long *>(a.ctrl + 192) + 8 + i, (unsigned long long)dg_acc[i]);
+#endif
+        return;
+    }
+
+    // ---------------- worker waves -------------------------------------------------------------------------
     // regroup constants: group g = 64*step + lane starts at stream bit 31*g; 64 groups = 1984 bits = 62 words
     // exactly, so the in-word shift is fixed per lane and the word index advances by 62 per step
     const u32 r = (31u * lane) & 31u;
-    const u32 stride = gridDim.x;
-    const u32 row_stride = (stride + 3u) & ~3u;
-    const u32 ww = worker ? wave : 0;
-    unsigned short *const pos = s_pos[ww];
+    unsigned short *const pos = s_pos[wave];
 
     Prefetch pre;
     pre.v[0] = pre.v[1] = pre.v[2] = pre.v[3] = make_uint4(0, 0, 0, 0);
     bool pre_valid = false; // wave-uniform: `pre` holds the current tile's segment
     {
         const u32 seg = arrival * W + wave;
-        if (worker && arrival < a.n_tiles && seg < a.fast_segments) {
+        if (arrival < a.n_tiles && seg < a.fast_segments) {
             prefetch_segment(a.in, seg, lane, pre);
             pre_valid = true;
         }
     }
 
-    GenScan scan = {0, 0, 0};
-    u32 prev_aggregate = 0; // scan wave: words of the previous tile (published, not yet resolved)
-    u32 prev_count = 0;     // worker: words of its previous segment (in LDS, not yet written out)
-    WAH_STAMP_DECL
-    u32 gen = 0, par = 0, slot3 = 0, prev_slot3 = 0;
-    for (u32 tile = arrival;; tile += stride, ++gen, par ^= 1u) {
+    u32 prev_count = 0; // words of this wave's previous segment (final, in LDS, not yet written out)
+    u32 gen = 0;
+    for (u32 tile = arrival;; tile += stride, ++gen) {
         const bool has_cur = tile < a.n_tiles;
         const bool has_prev = gen > 0;
-        const u32 seg = tile * W + wave; // workers only
-        u32 *const lds = s_out[par][ww];
+        const u32 seg = tile * W + wave;
+        u32 *const lds = s_out[gen & 1u][wave];
         u32 count = 0;
         // Opaque copy of the lane id, renewed every iteration: per-step constants derived from it (group
         // positions, LDS addresses) are then recomputed next to their use instead of being hoisted out of the
         // persistent loop, where 16 + 16 of them would be kept live and spilled.
         u32 lane_v = lane;
         asm volatile("" : "+v"(lane_v));
+#ifdef WAH_DIAG
+        if (threadIdx.x == 0 && has_cur && a.seg_offsets) a.seg_offsets[(u64)tile * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
 
-        if (worker) {
-            if (has_cur) {
-                if (seg < a.n_segments) {
-                    if (pre_valid)
-                        stage_prefetched(pre, lds, lane);
-                    else
-                        stage_slow(a, seg, lds, lane);
-                }
-                // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
+        if (has_cur) {
+            if (seg < a.n_segments) {
+                if (pre_valid)
+                    stage_prefetched(pre, lds, lane);
+                else
+                    stage_slow(a, seg, lds, lane);
+            }
+            // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            WAH_STAMP(0);
+
+            // software prefetch of the next tile's segment: in flight during everything below
+            {
+                const u32 next_tile = tile + stride;
+                const u32 nseg = next_tile * W + wave;
+                pre_valid = next_tile < a.n_tiles && nseg < a.fast_segments;
+                if (pre_valid) prefetch_segment(a.in, nseg, lane, pre);
+            }
+
+            const bool has_seg = seg < a.n_segments;
+            if (has_seg) {
+                const u32 nvalid = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
+                if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
+                const u32 *sp = lds + ((31u * lane_v) >> 5);
+                bool any_fill = false;
+                count = nvalid == kSegGroups ? classify_compact<true>(sp, lds, pos, r, lane_v, nvalid, any_fill)
+                                             : classify_compact<false>(sp, lds, pos, r, lane_v, nvalid, any_fill);
+                WAH_STAMP(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                WAH_STAMP(0);
-
-                // software prefetch of the next tile's segment: in flight during everything below
-                {
-                    const u32 next_tile = tile + stride;
-                    const u32 nseg = next_tile * W + wave;
-                    pre_valid = next_tile < a.n_tiles && nseg < a.fast_segments;
-                    if (pre_valid) prefetch_segment(a.in, nseg, lane, pre);
-                }
-
-                if (seg < a.n_segments) {
-                    const u32 nvalid = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
-                    if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
-                    const u32 *sp = lds + ((31u * lane_v) >> 5);
-                    count = nvalid == kSegGroups ? classify_compact<true>(sp, lds, pos, r, lane_v, nvalid)
-                                                 : classify_compact<false>(sp, lds, pos, r, lane_v, nvalid);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    // final words in place (kernels.cu:244-249): fill length = distance between consecutive run ends
-                    for (u32 j = lane; j < count; j += 64) {
-                        const u32 v = lds[j];
-                        const u32 len = ((u32)pos[j + 1] - (u32)pos[j]) & 0xFFFFu;
-                        lds[j] = v == 0u ? (kFillZero | len) : (v == kOnes31 ? (kFillOne | len) : v);
+                // final words in place (kernels.cu:244-249): fill length = distance between consecutive run
+                // ends; an all-literal segment (dense bitmaps) is final already
+                if (any_fill) {
+                    // four batches per trip: 12 LDS reads in flight, then the arithmetic, then 4 writes
+                    for (u32 j0 = lane; j0 < count; j0 += 256) {
+                        u32 v[4], p1[4], p0[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const u32 j = j0 + 64u * k;
+                            const bool in = j < count;
+                            v[k] = in ? lds[j] : 1u;
+                            p1[k] = in ? (u32)pos[j + 1] : 0u;
+                            p0[k] = in ? (u32)pos[j] : 0u;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const u32 j = j0 + 64u * k;
+                            const u32 len = (p1[k] - p0[k]) & 0xFFFFu;
+                            if (j < count && v[k] - 1u >= 0x7FFFFFFEu) lds[j] = (v[k] ? kFillOne : kFillZero) | len;
+                        }
                     }
                 }
-                WAH_STAMP(1);
-                if (lane == 0) s_count[slot3][wave] = count;
             }
-        } else if (has_prev) {
-            // scan wave: resolve the previous tile's output offset while the workers classify this one
-            // (replaces the scan + read-backs of compress.cu:133-157)
-            const u32 ptile = tile - stride;
-            const u64 excl = resolve_generation(a.gen_desc, gen - 1, arrival, stride, row_stride, prev_aggregate, scan,
-                                                lane, a.ctrl);
-            if (lane == 0) {
-                s_base[par ^ 1u] = excl;
-                if (ptile == a.n_tiles - 1) {
-                    *a.out_words = excl + prev_aggregate;
-                    if (a.seg_offsets) a.seg_offsets[a.n_segments] = excl + prev_aggregate;
-                }
-                if (excl + prev_aggregate > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
-            }
-        }
-        __syncthreads();
-        WAH_STAMP(2);
+            WAH_STAMP(5);
 
-        if (!worker) {
-            if (has_cur) {
-                const u32 mine = lane < (u32)W ? s_count[slot3][lane] : 0u;
-                prev_aggregate = uniform32(wave_sum32(mine));
-                if (lane == 0) publish_generation(a.gen_desc, gen, arrival, row_stride, prev_aggregate);
+            // deliver the count; the last worker to arrive publishes the tile's total to the other workgroups
+            // (one 4-byte granule, see resolve_generation) and to the scan wave
+            const u32 q = gen & 3u;
+            u32 last = 0;
+            if (lane == 0) {
+                lds_st(&s_count[q][wave], count);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                last = __hip_atomic_fetch_add((lds_u32_ptr)&s_arrived[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (u32)W - 1u;
             }
-        } else if (has_prev) {
-            // stream out the previous tile's words (kernels.cu:256 + moveData, kernels.cu:273-280)
+            if (uniform32(last)) {
+                const u32 mine = lane < (u32)W ? lds_ld(&s_count[q][lane]) : 0u;
+                const u32 total = uniform32(wave_sum32(mine));
+                if (lane == 0) {
+#ifdef WAH_DIAG
+                    if (a.seg_offsets) a.seg_offsets[(u64)tile * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+                    publish_generation(a.gen_desc, gen, arrival, row_stride, total);
+                    lds_st(&s_arrived[q], 0u);
+                    lds_st(&s_total[q], total);
+                    lds_publish(&s_total_flag[q], gen + 1u);
+                }
+            }
+            WAH_STAMP(2);
+        }
+
+        if (has_prev) {
+            // stream out the previous tile's words (kernels.cu:256 + moveData, kernels.cu:273-280): its offset has
+            // been resolved by the scan wave while this wave classified the current tile
+            const u32 pgen = gen - 1u;
             const u32 pseg = (tile - stride) * W + wave;
+            lds_wait(&s_base_flag[pgen & 1u], pgen + 1u, a.ctrl, lane);
+            WAH_STAMP(3);
             if (pseg < a.n_segments) {
-                u64 base = uniform64(s_base[par ^ 1u]);
-                for (u32 w = 0; w < wave; ++w) base += uniform32(s_count[prev_slot3][w]);
+                u64 base = uniform64(lds_ld64(&s_base[pgen & 1u]));
+                for (u32 w = 0; w < wave; ++w) base += uniform32(lds_ld(&s_count[pgen & 3u][w]));
+#ifndef WAH_DIAG
                 if (lane == 0 && a.seg_offsets) a.seg_offsets[pseg] = base;
+#endif
                 if (base + prev_count <= a.out_capacity) {
-                    const u32 *src = s_out[par ^ 1u][ww];
-                    u32 *dst = a.out + base;
-                    for (u32 j = lane; j < prev_count; j += 64) dst[j] = src[j];
+                    const u32 *src = s_out[pgen & 1u][wave];
+                    char *dst = reinterpret_cast<char *>(a.out + base); // wave-uniform base + 32-bit lane offset
+                    for (u32 j0 = lane; j0 < prev_count; j0 += 256) { // four LDS reads in flight, then four stores
+                        u32 v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = j0 + 64u * k < prev_count ? src[j0 + 64u * k] : 0u;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (j0 + 64u * k < prev_count) *reinterpret_cast<u32 *>(dst + (u64)((j0 + 64u * k) * 4u)) = v[k];
+                    }
                 }
             }
             // the iteration after next restages this buffer: order these reads before those writes
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            WAH_STAMP(4);
         }
-        WAH_STAMP(3);
         if (!has_cur) break;
         prev_count = count;
-        prev_slot3 = slot3;
-        slot3 = slot3 == 2 ? 0 : slot3 + 1;
 #ifdef WAH_DIAG
         dg_acc[7] += 1;
 #endif
     }
     WAH_STAMP_FLUSH(a.ctrl);
+#ifdef WAH_DIAG
+    if (lane == 0 && a.seg_offsets && blockIdx.x < 64) { // per-wave phase totals of the first 64 workgroups
+        for (int i = 0; i < 8; ++i)
+            a.seg_offsets[(u64)a.n_tiles * 4 + (u64)gridDim.x * 10 + ((u64)blockIdx.x * 16 + wave) * 8 + i] = dg_acc[i];
+    }
+    if (threadIdx.x == 0 && a.seg_offsets) {
+        u32 xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        for (int i = 0; i < 8; ++i) a.seg_offsets[(u64)a.n_tiles * 4 + (u64)blockIdx.x * 10 + i] = dg_acc[i];
+        a.seg_offsets[(u64)a.n_tiles * 4 + (u64)blockIdx.x * 10 + 8] = xcc;
+        a.seg_offsets[(u64)a.n_tiles * 4 + (u64)blockIdx.x * 10 + 9] = arrival;
+    }
+#endif
 }
 
 // ===========================================================================

@@ -11,7 +11,7 @@ os.environ["WAH_LIB_PATH"] = os.path.join(ROOT, "gpu-wah_amd", "libwah_hip_diag.
 import torch  # noqa: E402
 
 wah = importlib.import_module("gpu-wah_amd")
-names = ["wait loads + stage", "classify+compact", "count barrier", "look-back (scan wave)", "base barrier", "emit", "-", "tiles"]
+names = ["wait loads + stage", "prefetch + read + masks", "deliver count (+publish)", "wait for previous offset", "emit previous tile", "compact + finalize", "-", "tiles"]
 n = 268435200
 for kind in sys.argv[1:] or ["sparse", "dense", "clustered"]:
     d = {"sparse": lambda: wah.gen_uniform_device(n, 1337, 0.01), "dense": lambda: wah.gen_uniform_device(n, 1337, 0.5),
@@ -27,7 +27,5 @@ for kind in sys.argv[1:] or ["sparse", "dense", "clustered"]:
     print(f"--- {kind}: {tiles} tiles, {total / tiles:.0f} cycles/tile (thread 0 of each workgroup)")
     for nm, v in zip(names[:7], acc[:7]):
         print(f"   {nm:18s} {v / tiles:9.0f} cyc/tile  {100.0 * v / total:5.1f} %")
-    st = max(acc[11], 1)
-    print(f"   scan wave: ticket {acc[8] / st:.0f} cyc, wait-for-workers {acc[9] / st:.0f} cyc, look-back {acc[10] / st:.0f} cyc per tile; "
-          f"poll rounds/tile {acc[12] / st:.2f} (intra pending {acc[13] / st:.2f}, blocks pending {acc[14] / st:.2f})")
+    print(f"   scan wave per tile: wait for counts {acc[8] / tiles:.0f} cyc, resolve {acc[9] / tiles:.0f} cyc")
     del comp, d
