@@ -49,24 +49,20 @@ CompressLayout compress_layout(uint64_t n_words) {
 }
 
 struct DecodeLayout {
-    uint64_t n_tiles, max_segments, seg_capacity;
-    size_t ctrl_off, desc_off, block_off, seg_word_off, seg_skip_off, total, zero_bytes;
+    uint64_t n_tiles;
+    size_t ctrl_off, desc_off, big_off, base_off, total, zero_bytes;
 };
 
-DecodeLayout decode_layout(uint64_t c_words, uint64_t out_capacity_words) {
+DecodeLayout decode_layout(uint64_t c_words) {
     DecodeLayout l;
     l.n_tiles = ceil_div(c_words, (uint64_t)wah::kScanTileWords);
-    // G groups decode to ceil(31 G / 32) words: at most floor(32 cap / 31) groups fit
-    const uint64_t max_groups = out_capacity_words * 32u / 31u;
-    l.max_segments = ceil_div(max_groups, wah::kSegGroups);
-    l.seg_capacity = l.max_segments + 1;
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
-    l.block_off = round256(l.desc_off + (l.n_tiles + 1) * sizeof(uint64_t));
-    l.zero_bytes = round256(l.block_off + (l.n_tiles / 32 + 2) * sizeof(uint64_t));
-    l.seg_word_off = l.zero_bytes;
-    l.seg_skip_off = round256(l.seg_word_off + l.seg_capacity * sizeof(uint64_t));
-    l.total = round256(l.seg_skip_off + l.seg_capacity * sizeof(uint32_t));
+    // generation rows, as in compress_layout(): at most 4 * n_tiles + 8 granules
+    l.zero_bytes = round256(l.desc_off + (4 * l.n_tiles + 8) * sizeof(uint32_t));
+    l.big_off = l.zero_bytes;
+    l.base_off = round256(l.big_off + (l.n_tiles + 1) * sizeof(uint64_t));
+    l.total = round256(l.base_off + (l.n_tiles + 2) * sizeof(uint64_t));
     return l;
 }
 
@@ -162,7 +158,8 @@ uint64_t wah_decoded_words(uint64_t n_groups) { return (31u * n_groups + 31u) / 
 
 size_t wah_compress_workspace_bytes(uint64_t n_words) { return compress_layout(n_words).total; }
 size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_words) {
-    return decode_layout(c_words, out_capacity_words).total;
+    (void)out_capacity_words; // the workspace depends on the stream length only
+    return decode_layout(c_words).total;
 }
 
 int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
@@ -252,45 +249,59 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         set_err("size out of range or misaligned pointer");
         return WAH_ERR_ARG;
     }
-    const DecodeLayout l = decode_layout(c_words, out_capacity_words);
+    const DecodeLayout l = decode_layout(c_words);
     if (workspace_bytes < l.total) {
         set_err("workspace too small");
         return WAH_ERR_WORKSPACE;
+    }
+    if (l.n_tiles >= (1ull << 31)) {
+        set_err("stream too long");
+        return WAH_ERR_ARG;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(d_workspace);
     hipError_t e = hipSuccess;
     if (do_scan) {
-        e = hipMemsetAsync(ws, 0, l.zero_bytes, s);
+        const int resident = c_words ? wah::decode_sums_grid(reinterpret_cast<uint32_t *>(ws), s) : 1;
+        if (resident < 1) {
+            set_err("residency census failed", hipGetLastError());
+            return WAH_ERR_HIP;
+        }
+        // the sums kernel works on workgroup tiles of kSumTilesPerGroup expand tiles
+        const uint64_t wg_tiles = ceil_div(l.n_tiles, (uint64_t)wah::kSumTilesPerGroup);
+        uint64_t grid64 = (uint64_t)resident < wg_tiles ? (uint64_t)resident : (wg_tiles ? wg_tiles : 1);
+        if (const char *dbg = std::getenv("WAH_SUMS_GRID")) {
+            const uint64_t g = std::strtoull(dbg, nullptr, 10);
+            if (g >= 1 && g < grid64) grid64 = g;
+        }
+        const uint64_t generations = (wg_tiles + grid64 - 1) / grid64;
+        const size_t used = round256(l.desc_off + (generations * ((grid64 + 3) & ~3ull) + 8) * sizeof(uint32_t));
+        e = hipMemsetAsync(ws, 0, used < l.zero_bytes ? used : l.zero_bytes, s);
         if (e == hipSuccess && c_words == 0) e = hipMemsetAsync(d_out_info, 0, 2 * sizeof(uint64_t), s);
         if (e != hipSuccess) {
             set_err("hipMemsetAsync", e);
             return WAH_ERR_HIP;
         }
-    }
-    if (c_words == 0) return WAH_OK;
-    if (do_scan) {
-        wah::ScanArgs a;
-        a.comp = d_comp;
-        a.c_words = c_words;
-        a.n_tiles = l.n_tiles;
-        a.info = d_out_info;
-        a.seg_word = reinterpret_cast<uint64_t *>(ws + l.seg_word_off);
-        a.seg_skip = reinterpret_cast<uint32_t *>(ws + l.seg_skip_off);
-        a.seg_capacity = l.seg_capacity;
-        a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
-        a.desc = reinterpret_cast<uint64_t *>(ws + l.desc_off);
-        a.block_desc = reinterpret_cast<uint64_t *>(ws + l.block_off);
-        a.aligned16 = aligned16(d_comp) ? 1 : 0;
-        static thread_local int grid_cache = 0;
-        if (!grid_cache) grid_cache = wah::decode_scan_grid(~0ull);
-        const int grid = (uint64_t)grid_cache < l.n_tiles ? grid_cache : (int)l.n_tiles;
-        e = wah::launch_decode_scan(a, grid, s);
-        if (e != hipSuccess) {
-            set_err("decode scan kernel launch", e);
-            return WAH_ERR_HIP;
+        if (c_words) {
+            wah::ScanArgs a;
+            a.comp = d_comp;
+            a.c_words = c_words;
+            a.n_tiles = l.n_tiles;
+            a.info = d_out_info;
+            a.tile_base = reinterpret_cast<uint64_t *>(ws + l.base_off);
+            a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
+            a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
+            a.big = reinterpret_cast<uint64_t *>(ws + l.big_off);
+            a.aligned16 = aligned16(d_comp) ? 1 : 0;
+            a.census = 0;
+            e = wah::launch_decode_sums(a, (int)grid64, s);
+            if (e != hipSuccess) {
+                set_err("decode sums kernel launch", e);
+                return WAH_ERR_HIP;
+            }
         }
     }
+    if (c_words == 0) return WAH_OK;
     if (do_expand) {
         wah::ExpandArgs x;
         x.comp = d_comp;
@@ -298,11 +309,10 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         x.out = d_out;
         x.out_capacity = out_capacity_words;
         x.info = d_out_info;
-        x.seg_word = reinterpret_cast<const uint64_t *>(ws + l.seg_word_off);
-        x.seg_skip = reinterpret_cast<const uint32_t *>(ws + l.seg_skip_off);
-        x.seg_capacity = l.seg_capacity;
+        x.tile_base = reinterpret_cast<const uint64_t *>(ws + l.base_off);
         x.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
-        e = wah::launch_decode_expand(x, l.max_segments, s);
+        x.aligned16 = aligned16(d_comp) ? 1 : 0;
+        e = wah::launch_decode_expand(x, l.n_tiles, s);
         if (e != hipSuccess) {
             set_err("decode expand kernel launch", e);
             return WAH_ERR_HIP;
@@ -319,7 +329,6 @@ int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_
 
 int wah_decompress_scan_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_out_info, void *d_workspace,
                                size_t workspace_bytes, void *stream) {
-    // sized for "no output": the segment index is not kept, only the totals
     return decode_common(d_comp, c_words, nullptr, 0, d_out_info, d_workspace, workspace_bytes, stream, true, false);
 }
 
@@ -463,13 +472,12 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
         return nullptr;
     }
     const uint64_t n_out = info[0], groups = info[1];
-    void *d_out = nullptr, *d_ws = nullptr;
-    const size_t ws = wah_decompress_workspace_bytes(c_words, n_out);
+    void *d_out = nullptr;
     if (!hc.alloc(&d_out, n_out * sizeof(uint32_t), "space for the result")) return nullptr;
-    if (!hc.alloc(&d_ws, ws, "workspace")) return nullptr;
-    rc = wah_decompress_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(d_out), n_out,
-                               static_cast<uint64_t *>(d_info), d_ws, ws, nullptr);
-    if (rc == WAH_OK) rc = wah_decompress_status(d_ws, nullptr);
+    // the tile bases of the scan are still in the workspace: expand only
+    rc = wah_decompress_expand_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(d_out), n_out,
+                                      static_cast<uint64_t *>(d_info), d_ws0, ws0, nullptr);
+    if (rc == WAH_OK) rc = wah_decompress_status(d_ws0, nullptr);
     if (rc != WAH_OK) {
         std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
         return nullptr;

@@ -42,11 +42,10 @@ constexpr uint64_t kValueMask = (1ull << kStatusShift) - 1;
 constexpr int kCompressWavesDefault = 15;
 int compress_workers();
 
-// ---- decode scan geometry -------------------------------------------------
-constexpr int kScanThreads = 256;
-constexpr int kScanWordsPerThread = 16;
-constexpr int kScanTileWords = kScanThreads * kScanWordsPerThread; // 4096
-constexpr int kExpandWaves = 4;                                    // segments per workgroup
+// ---- decode geometry -------------------------------------------------------
+constexpr int kScanTileWords = 4096; // compressed words per tile (both decode passes)
+constexpr int kSumTilesPerGroup = 8;  // expand tiles per workgroup tile of the sums kernel (= its worker waves)
+constexpr int kExpandWaves = 4;      // wavefronts of an expand workgroup (each expands whole segments)
 
 struct CompressArgs {
     const uint32_t *in;
@@ -69,13 +68,12 @@ struct ScanArgs {
     uint64_t c_words;
     uint64_t n_tiles;
     uint64_t *info;      // [0] decoded words, [1] groups
-    uint64_t *seg_word;  // per output segment: index of the word holding its first group
-    uint32_t *seg_skip;  // ... and how many of that word's groups belong to earlier segments
-    uint64_t seg_capacity;
+    uint64_t *tile_base; // n_tiles + 1: groups in front of each tile, last = total
     uint32_t *ctrl;
-    uint64_t *desc;
-    uint64_t *block_desc;
+    uint32_t *gen_desc;  // generation rows (4-byte granules)
+    uint64_t *big;       // 64-bit side entries for totals that do not fit a granule
     int aligned16;
+    int census;
 };
 
 struct ExpandArgs {
@@ -84,18 +82,17 @@ struct ExpandArgs {
     uint32_t *out;
     uint64_t out_capacity;
     const uint64_t *info;
-    const uint64_t *seg_word;
-    const uint32_t *seg_skip;
-    uint64_t seg_capacity;
+    const uint64_t *tile_base;
     uint32_t *ctrl;
+    int aligned16;
 };
 
 // launchers (wah_kernels.hip)
 hipError_t launch_compress(int workers, const CompressArgs &a, int grid, hipStream_t s);
 int compress_grid(int workers, uint32_t *d_ctrl, hipStream_t s);
-hipError_t launch_decode_scan(const ScanArgs &a, int grid, hipStream_t s);
-int decode_scan_grid(uint64_t n_tiles);
-hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t max_segments, hipStream_t s);
+hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s);
+int decode_sums_grid(uint32_t *d_ctrl, hipStream_t s);
+hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t n_tiles, hipStream_t s);
 hipError_t launch_gen_uniform(uint32_t *out, uint64_t n, uint64_t seed, uint64_t thr, hipStream_t s);
 hipError_t launch_gen_clustered(uint32_t *out, uint64_t n, uint64_t seed, uint64_t thr, hipStream_t s);
 hipError_t launch_copy(const uint32_t *in, uint32_t *out, uint64_t n, hipStream_t s);

@@ -89,6 +89,18 @@ __device__ __forceinline__ u64 wave_scan_incl(u64 v, u32 lane) {
     return v;
 }
 
+// inclusive prefix sum of a u32 across the 64 lanes with DPP only (no LDS crossbar): Hillis-Steele inside each
+// row of 16 lanes (row_shr 1,2,4,8, zero fill), then row_bcast:15 into rows 1 and 3, then row_bcast:31 into rows 2-3
+__device__ __forceinline__ u32 wave_scan_incl32(u32 v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 // Values read back from LDS are wave-uniform here by construction; readfirstlane tells the compiler so, which
 // keeps everything derived from them (segment numbers, masks, offsets, branches) on the scalar unit.
 __device__ __forceinline__ u32 uniform32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
@@ -462,6 +474,23 @@ __device__ __forceinline__ bool lds_wait(const u32 *flag, u32 value, u32 *ctrl, 
     return true;
 }
 
+// same, for a monotonic progress counter: wait until it has reached `value`
+__device__ __forceinline__ bool lds_wait_reached(const u32 *counter, u32 value, u32 *ctrl) {
+    if ((int)(lds_ld(counter) - value) < 0) {
+        __builtin_amdgcn_s_setprio(0);
+        for (u32 spins = 0; (int)(lds_ld(counter) - value) < 0;) {
+            if (++spins > kMaxSpins) {
+                atomicOr(ctrl + kCtlError, kErrTimeout);
+                return false;
+            }
+            __builtin_amdgcn_s_sleep(6);
+        }
+        __builtin_amdgcn_s_setprio(1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return true;
+}
+
 template <int W>
 __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_out[2][W][kStageWords];
@@ -490,12 +519,15 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
     if (a.census) {
         // residency census: how many workgroups of this kernel are running together?  Everybody that is resident
         // arrives within about a microsecond; whoever is not cannot start before a resident one exits.
+        // EVERY wave stays for the whole census (the barrier below): a wave that left early would give back its
+        // slot and registers, and more workgroups would fit than in the real run.
         if (threadIdx.x == 0) {
             const u64 t0 = __builtin_amdgcn_s_memrealtime();
             while (__builtin_amdgcn_s_memrealtime() - t0 < 3000) __builtin_amdgcn_s_sleep(8); // 30 us (100 MHz)
             if (arrival == 0)
                 a.ctrl[kCtlCensus] = __hip_atomic_load(a.ctrl + kCtlStart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __syncthreads();
         return;
     }
 
@@ -712,183 +744,393 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
 }
 
 // ===========================================================================
-// decompress, pass 1: per-word group counts, their exclusive scan (look-back)
-// and the segment index.  Replaces getCounts + thrust::exclusive_scan
-// (kernels.cu:291-309, decompress.cu:72-82) without the 8-bytes-per-word
-// counts array: only one 12-byte record per OUTPUT segment is written.
+// decompress
+//
+// The reference runs getCounts -> thrust::exclusive_scan over one u64 PER COMPRESSED WORD -> decompressWords (a
+// serial fill loop per thread into a 4-byte-per-group intermediate) -> mergeWords (kernels.cu:291-385,
+// decompress.cu:66-115).  Here:
+//   pass 1  decode_sums_kernel   : streaming reduce.  Tiles of 4096 compressed words; per tile the number of 31-bit
+//                                   groups it expands to, turned into exclusive tile bases by the same one-hop
+//                                   generation scan as compress.  Reads C once, writes 8 bytes per tile.
+//   pass 2  decode_expand_kernel : one workgroup per tile, tile words resident in LDS.  A tile OWNS the output
+//                                   segments (1024 groups -> 992 words) whose first group falls into it; each of its
+//                                   wavefronts expands whole segments: group -> source word by RANK (mbcnt over a
+//                                   1024-bit mask of word starts), fill / literal decode, 31 -> 32 repack in
+//                                   registers with two DPP shifts, dense 248-byte stores.
+// Any stream the reference decoder accepts is handled (arbitrary 30-bit counts, fills across segment boundaries).
 // ===========================================================================
 __device__ __forceinline__ u32 word_groups(u32 w) {
     return (w & kFillZero) ? (w & kCountMask) : 1u; // kernels.cu:298-304
 }
 
-__global__ __launch_bounds__(kScanThreads) void decode_scan_kernel(const ScanArgs a) {
-    __shared__ u64 s_wave_sum[kScanThreads / 64];
-    __shared__ u64 s_tile;
-    __shared__ u64 s_base;
+constexpr u32 kGenEscape = 0x7FFFFFFFu; // granule value: "total does not fit 31 bits, read the 64-bit side entry"
+
+// generation scan with 64-bit totals (a tile of fills can expand to more than 2^31 groups)
+__device__ __forceinline__ u64 resolve_generation64(const u32 *gdesc, const u64 *big, u32 gen, u32 slot, u32 G,
+                                                    u32 row_stride, u64 aggregate, GenScan &st, u64 &own_prev64,
+                                                    u64 &below_prev64, u32 lane, u32 *ctrl) {
+    const u32 *cur = gdesc + (u64)gen * row_stride;
+    const u32 *prv = cur - row_stride;
+    bool need_prev = gen > 0 && slot + 1 < G, need_cur = slot > 0;
+    u64 above = 0, below = 0;
+    u32 spins = 0;
+    while (need_prev || need_cur) {
+        u64 sum_cur = 0, sum_prev = 0;
+        bool bad_cur = false, bad_prev = false;
+        for (u32 k = lane; k < G; k += 64u) {
+            if (need_cur && k < slot) {
+                const u32 e = __hip_atomic_load(cur + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad_cur |= !(e & kGenValid);
+                u64 v = e & ~kGenValid;
+                if (v == kGenEscape && (e & kGenValid))
+                    v = __hip_atomic_load(big + ((u64)gen * G + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sum_cur += v;
+            }
+            if (need_prev && k > slot) {
+                const u32 e = __hip_atomic_load(prv + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad_prev |= !(e & kGenValid);
+                u64 v = e & ~kGenValid;
+                if (v == kGenEscape && (e & kGenValid))
+                    v = __hip_atomic_load(big + ((u64)(gen - 1) * G + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sum_prev += v;
+            }
+        }
+        bool progressed = false;
+        if (need_cur && !__any(bad_cur)) {
+            below = uniform64(wave_sum(sum_cur));
+            need_cur = false;
+            progressed = true;
+        }
+        if (need_prev && !__any(bad_prev)) {
+            above = uniform64(wave_sum(sum_prev));
+            need_prev = false;
+            progressed = true;
+        }
+        if (!progressed) {
+            if (++spins > kMaxSpins) {
+                if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (gen > 0) st.gen_base += below_prev64 + own_prev64 + above;
+    below_prev64 = below;
+    own_prev64 = aggregate;
+    return st.gen_base + below;
+}
+
+// Workgroup = kSumWorkers worker wavefronts + 1 scan wave.  A worker sums one whole expand tile (4096 words) per
+// iteration in four rolling 4 KiB rounds; the workgroup's tile (kSumWorkers expand tiles, 128 KiB) costs ONE
+// granule, so the scan traffic stays below 1 % of the stream.
+constexpr int kSumWorkers = kSumTilesPerGroup;
+
+__global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(const ScanArgs a) {
+    __shared__ u64 s_part[4][kSumWorkers];
+    __shared__ u32 s_arrived[4];
+    __shared__ u64 s_total[4];
+    __shared__ u32 s_total_flag[4];
+    __shared__ u32 s_scanned; // tiles the scan wave has consumed (flow control of the 4-deep hand-off ring)
+    __shared__ u32 s_arrival;
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
+    const bool worker = wave < (u32)kSumWorkers;
 
-    if (threadIdx.x == 0) s_tile = draw_arrival(a.ctrl);
+    if (threadIdx.x < 4) {
+        s_arrived[threadIdx.x] = 0;
+        s_total_flag[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) {
+        s_scanned = 0;
+        s_arrival = draw_arrival(a.ctrl);
+    }
     __syncthreads();
-    const u32 shard = (u32)s_tile % kShards;
-    __syncthreads();
-
-    for (;;) {
-        if (threadIdx.x == 0) s_tile = draw_tile(a.ctrl, shard);
+    const u32 arrival = uniform32(s_arrival);
+    if (a.census) {
+        if (threadIdx.x == 0) { // residency census, see compress_kernel
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 3000) __builtin_amdgcn_s_sleep(8);
+            if (arrival == 0)
+                a.ctrl[kCtlCensus] = __hip_atomic_load(a.ctrl + kCtlStart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
-        const u64 tile = s_tile;
-        if (tile >= a.n_tiles) break;
+        return;
+    }
+    const u32 stride = gridDim.x;
+    const u32 row_stride = (stride + 3u) & ~3u;
+    const u32 n_tiles = (u32)a.n_tiles;                                      // expand tiles (4096 words)
+    const u32 n_wg_tiles = (n_tiles + (u32)kSumWorkers - 1u) / (u32)kSumWorkers; // workgroup tiles
 
-        // thread t owns 16 consecutive words: four 16-byte loads
-        const u64 w0 = tile * kScanTileWords + (u64)threadIdx.x * kScanWordsPerThread;
-        u32 w[kScanWordsPerThread];
-        if (a.aligned16 && w0 + kScanWordsPerThread <= a.c_words) {
+    if (!worker) {
+        // scan wave: workgroup-tile totals -> exclusive bases; then the bases of the expand tiles inside
+        GenScan scan = {0, 0, 0};
+        u64 own_prev = 0, below_prev = 0;
+        u32 gen = 0;
+        for (u32 wt = arrival; wt < n_wg_tiles; wt += stride, ++gen) {
+            const u32 q = gen & 3u;
+            if (!lds_wait(&s_total_flag[q], gen + 1u, a.ctrl, lane)) break;
+            const u64 total = uniform64(lds_ld64(&s_total[q]));
+            const u64 part = lane < (u32)kSumWorkers ? lds_ld64(&s_part[q][lane]) : 0ull;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_st(&s_scanned, gen + 1u); // the ring slot may be reused
+            const u64 excl = resolve_generation64(a.gen_desc, a.big, gen, arrival, stride, row_stride, total, scan, own_prev,
+                                                  below_prev, lane, a.ctrl);
+            // lane w: groups in front of expand tile wt * kSumWorkers + w
+            const u64 incl_part = wave_scan_incl(part, lane);
+            const u32 et = wt * (u32)kSumWorkers + lane;
+            if (lane < (u32)kSumWorkers && et < n_tiles) a.tile_base[et] = excl + (incl_part - part);
+            if (lane == 0 && wt == n_wg_tiles - 1) {
+                const u64 groups = excl + total;
+                a.tile_base[n_tiles] = groups;
+                a.info[1] = groups;
+                a.info[0] = (31ull * groups + 31ull) / 32ull; // decompress.cu:84-93
+            }
+        }
+        return;
+    }
+
+    // worker waves: stream one expand tile per iteration, sum the group counts (getCounts, kernels.cu:291-309)
+    uint4 pre[4];
+    // round `rd` (0..3) of expand tile `et`: 1024 words as four fully coalesced 1 KiB loads (order is irrelevant)
+    auto load_round = [&](u32 et, u32 rd) {
+        const u64 w0 = (u64)et * kScanTileWords + (u64)rd * 1024u;
+        if (a.aligned16 && w0 + 1024u <= a.c_words) {
             const uint4 *src = reinterpret_cast<const uint4 *>(a.comp + w0);
 #pragma unroll
-            for (int k = 0; k < kScanWordsPerThread / 4; ++k) {
-                const uint4 v = src[k];
-                w[4 * k + 0] = v.x;
-                w[4 * k + 1] = v.y;
-                w[4 * k + 2] = v.z;
-                w[4 * k + 3] = v.w;
-            }
+            for (int k = 0; k < 4; ++k) pre[k] = src[k * 64 + (int)lane];
         } else {
+            u32 t[16];
 #pragma unroll
-            for (int k = 0; k < kScanWordsPerThread; ++k) w[k] = (w0 + k < a.c_words) ? a.comp[w0 + k] : 0u;
+            for (int k = 0; k < 16; ++k) {
+                const u64 i = w0 + (u64)(k / 4) * 256u + (u64)lane * 4u + (u64)(k % 4);
+                t[k] = i < a.c_words ? a.comp[i] : 0x80000000u; // past the end: a fill of zero groups
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pre[k] = make_uint4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
         }
+    };
+    if (arrival < n_wg_tiles) load_round(arrival * (u32)kSumWorkers + wave, 0);
+    u32 gen = 0;
+    for (u32 wt = arrival; wt < n_wg_tiles; wt += stride, ++gen) {
+        const u32 et = wt * (u32)kSumWorkers + wave;
         u64 mine = 0;
 #pragma unroll
-        for (int k = 0; k < kScanWordsPerThread; ++k) mine += (w0 + k < a.c_words) ? word_groups(w[k]) : 0u;
-
-        const u64 incl = wave_scan_incl(mine, lane);
-        if (lane == 63) s_wave_sum[wave] = incl;
-        __syncthreads();
-
-        if (wave == 0) {
-            const u64 ws = lane < kScanThreads / 64 ? s_wave_sum[lane] : 0ull;
-            const u64 aggregate = wave_sum(ws);
-            const u64 excl = resolve_tile_prefix(a.desc, a.block_desc, tile, aggregate, lane, a.ctrl);
-            if (lane == 0) {
-                s_base = excl;
-                if (tile == a.n_tiles - 1) {
-                    const u64 groups = excl + aggregate;
-                    a.info[1] = groups;
-                    a.info[0] = (31ull * groups + 31ull) / 32ull; // decompress.cu:84-93
-                }
-            }
-        }
-        __syncthreads();
-
-        u64 pos = s_base + (incl - mine);
-        for (u32 k = 0; k < wave; ++k) pos += s_wave_sum[k];
-
-        // segment index: for every 1024-group boundary that falls inside a word, record the word and
-        // how many of its groups lie before the boundary.  Reference streams cut fills at boundaries
-        // (kernels.cu:188-229), so there it is at most one record per word with skip = 0; foreign
-        // streams with long fills (decoder accepts any 30-bit count, kernels.cu:334) take the loop.
+        for (u32 rd = 0; rd < 4; ++rd) {
+            uint4 cur[4];
 #pragma unroll
-        for (int k = 0; k < kScanWordsPerThread; ++k) {
-            if (w0 + k < a.c_words) {
-                const u64 n = word_groups(w[k]);
-                u64 b = (pos + kSegGroups - 1) / kSegGroups;
-                for (; b * kSegGroups < pos + n; ++b) {
-                    if (b < a.seg_capacity) {
-                        a.seg_word[b] = w0 + k;
-                        a.seg_skip[b] = (u32)(b * kSegGroups - pos);
-                    }
+            for (int k = 0; k < 4; ++k) cur[k] = pre[k];
+            // rolling prefetch: next round of this tile, or round 0 of this wave's next tile
+            if (rd < 3)
+                load_round(et, rd + 1);
+            else if (wt + stride < n_wg_tiles)
+                load_round((wt + stride) * (u32)kSumWorkers + wave, 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) // four counts of < 2^30 each fit 32 bits; words past the end are empty fills
+                mine += (u64)(word_groups(cur[k].x) + word_groups(cur[k].y) + word_groups(cur[k].z) + word_groups(cur[k].w));
+        }
+        const u64 wave_total = uniform64(wave_sum(mine));
+        const u32 q = gen & 3u;
+        u32 last = 0;
+        if (lane == 0) {
+            // the ring slot is free once the scan wave has consumed the tile that used it 4 generations ago
+            if (gen >= 4) lds_wait_reached(&s_scanned, gen - 3u, a.ctrl);
+            __hip_atomic_store((lds_u64_ptr)&s_part[q][wave], wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            last = __hip_atomic_fetch_add((lds_u32_ptr)&s_arrived[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ==
+                   (u32)kSumWorkers - 1u;
+        }
+        if (uniform32(last)) {
+            if (lane == 0) {
+                u64 total = 0;
+#pragma unroll
+                for (int w = 0; w < kSumWorkers; ++w) total += lds_ld64(&s_part[q][w]);
+                // publish: one 4-byte granule; totals of 2^31 - 1 groups or more go through the 64-bit side entry
+                if (total >= kGenEscape) {
+                    __hip_atomic_store(a.big + ((u64)gen * stride + arrival), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    publish_generation(a.gen_desc, gen, arrival, row_stride, kGenEscape);
+                } else {
+                    publish_generation(a.gen_desc, gen, arrival, row_stride, (u32)total);
                 }
-                pos += n;
+                lds_st(&s_arrived[q], 0u);
+                __hip_atomic_store((lds_u64_ptr)&s_total[q], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_publish(&s_total_flag[q], gen + 1u);
             }
         }
     }
 }
 
-// ===========================================================================
-// decompress, pass 2: output-stationary expansion.  One wavefront produces one
-// output segment (1024 groups -> 992 words), whatever mix of fills and literals
-// feeds it: no per-thread serial fill loop (kernels.cu:346-348), no 4-byte-per-
-// group intermediate (decompress.cu:97) and no separate mergeWords pass
-// (kernels.cu:369-385) -- the 31->32 repack happens in registers.
-// ===========================================================================
-__global__ __launch_bounds__(kExpandWaves * 64) void decode_expand_kernel(const ExpandArgs a) {
-    __shared__ u32 s_val[kExpandWaves][kSegGroups];      // word that starts a run at group p
-    __shared__ u32 s_mark[kExpandWaves][kSegGroups / 32]; // bit p set: a word starts at group p
+// ---------------------------------------------------------------------------
+// pass 2
+// ---------------------------------------------------------------------------
+constexpr int kExpandThreads = kExpandWaves * 64;                 // 256
+constexpr int kExpandWordsPerThread = kScanTileWords / kExpandThreads; // 16
+constexpr u32 kCoarse = kScanTileWords / 64;                      // coarse prefix: one entry per 64 words
+
+// word `idx` (tile-local index) of the stream: LDS inside the tile, global memory past its end
+__device__ __forceinline__ u32 tile_word(const u32 *s_words, const ExpandArgs &a, u64 tile_w0, u32 idx) {
+    if (idx < (u32)kScanTileWords) return s_words[idx];
+    const u64 g = tile_w0 + idx;
+    return g < a.c_words ? a.comp[g] : 0u;
+}
+
+__global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const ExpandArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 s_words[kScanTileWords];
+    __shared__ u64 s_coarse[kCoarse + 1]; // groups in front of word 64 c, relative to the tile start
+    __shared__ u64 s_wave_sum[kExpandWaves];
+    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][kSegGroups]; // 1: a word starts at this group
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
+    const u32 tile = blockIdx.x;
+    const u64 tile_w0 = (u64)tile * kScanTileWords;
     const u64 groups = a.info[1];
     const u64 out_words = a.info[0];
-    const u64 n_seg = (groups + kSegGroups - 1) / kSegGroups;
-    const u64 seg = (u64)blockIdx.x * kExpandWaves + wave;
-    if (seg >= n_seg || seg >= a.seg_capacity) return; // wave-uniform
     if (out_words > a.out_capacity) {
-        if (lane == 0 && seg == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+        if (threadIdx.x == 0 && tile == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
         return;
     }
 
-    u32 *val = s_val[wave];
-    u32 *mark = s_mark[wave];
-    if (lane < kSegGroups / 32) mark[lane] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-    const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
-    u64 wi = a.seg_word[seg];
-    u32 skip = a.seg_skip[seg];
-
-    // scatter run starts: each lane takes one compressed word per round
-    u32 filled = 0;
-    while (filled < nvalid && wi < a.c_words) {
-        const u64 i = wi + lane;
-        u32 w = 0;
-        u64 n = 0;
-        if (i < a.c_words) {
-            w = a.comp[i];
-            n = word_groups(w);
-            if (lane == 0) n = n > skip ? n - skip : 0u; // groups of the first word already emitted earlier
-        }
-        const u64 incl = wave_scan_incl(n, lane);
-        const u64 p = (u64)filled + (incl - n);
-        if (n != 0u && p < nvalid) {
-            val[p] = w;
-            atomicOr(&mark[p >> 5], 1u << (p & 31u));
-        }
-        const u64 total = (u64)filled + __shfl(incl, 63);
-        filled = total > kSegGroups ? kSegGroups : (u32)total;
-        wi += 64;
-        skip = 0;
+    // ---- stage the tile and build the coarse prefix of group counts --------------------------------------------
+    constexpr int kVec = kExpandWordsPerThread / 4;
+    if (a.aligned16 && tile_w0 + kScanTileWords <= a.c_words) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.comp + tile_w0);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_words);
+        uint4 v[kVec];
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) v[k] = src[k * kExpandThreads + (int)threadIdx.x]; // coalesced 16-byte loads
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) dst[k * kExpandThreads + (int)threadIdx.x] = v[k];
+    } else {
+        for (u32 i = threadIdx.x; i < (u32)kScanTileWords; i += kExpandThreads)
+            s_words[i] = tile_w0 + i < a.c_words ? a.comp[tile_w0 + i] : 0x80000000u; // past the end: empty fill
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (filled < nvalid) {
-        if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
-        return;
+    __syncthreads();
+    // every thread sums the counts of its own 16 consecutive words
+    u64 mine = 0;
+    {
+        const uint4 *my = reinterpret_cast<const uint4 *>(s_words + threadIdx.x * kExpandWordsPerThread);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) {
+            const uint4 q = my[k];
+            mine += (u64)(word_groups(q.x) + word_groups(q.y) + word_groups(q.z) + word_groups(q.w));
+        }
     }
+    const u64 incl = wave_scan_incl(mine, lane);
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    u64 excl = incl - mine;
+    for (u32 k = 0; k < wave; ++k) excl += s_wave_sum[k];
+    constexpr u32 kThreadsPer64 = 64 / kExpandWordsPerThread;
+    if (threadIdx.x % kThreadsPer64 == 0) s_coarse[threadIdx.x / kThreadsPer64] = excl; // first thread of each 64 words
+    if (threadIdx.x == kExpandThreads - 1) s_coarse[kCoarse] = excl + mine;
+    __syncthreads();
 
-    // every lane finds the run its group belongs to: nearest mark at or below the group
-    const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const u64 out0 = seg * kSegWords;
-    int last_mark = 0;
-#pragma unroll 4
-    for (int s = 0; s < (int)kSteps; ++s) {
-        const u64 m = (u64)mark[2 * s] | ((u64)mark[2 * s + 1] << 32); // same address in all lanes: broadcast
-        const u64 mine = m & le;
-        const int src = mine ? (64 * s + 63 - (int)__clzll((long long)mine)) : last_mark;
-        if (m) last_mark = 64 * s + 63 - (int)__clzll((long long)m);
-        const u32 w = val[src];
-        u32 grp = (w & kFillZero) ? ((w & 0x40000000u) ? kOnes31 : 0u) : w; // kernels.cu:332-354
-        if ((u32)(64 * s) + lane >= nvalid) grp = 0u;
+    // ---- segments owned by this tile: those whose first group lies in [base, base + total) ----------------------
+    const u64 base = a.tile_base[tile];
+    const u64 total = uniform64(s_coarse[kCoarse]);
+    const u64 n_seg = (groups + kSegGroups - 1) / kSegGroups;
+    const u64 k_begin = (base + kSegGroups - 1) / kSegGroups;
+    u64 k_end = (base + total + kSegGroups - 1) / kSegGroups;
+    if (k_end > n_seg) k_end = n_seg;
 
-        // 31 -> 32 repack (mergeWords, kernels.cu:375): output word 62*s + l takes stream bits
-        // [32*(62 s + l), +32) = groups 64 s + l + (l >= 31) and the next one, shifted by l mod 31
-        const u32 g1 = __shfl_down(grp, 1);
-        const u32 g2 = __shfl_down(grp, 2);
-        const bool hiHalf = lane >= 31;
-        const u32 a0 = hiHalf ? g1 : grp;
-        const u32 a1 = hiHalf ? g2 : g1;
-        const u32 o = hiHalf ? lane - 31 : lane;
-        const u32 word = (a0 >> o) | (a1 << (31u - o));
-        const u64 idx = out0 + 62u * s + lane;
-        if (lane < 62 && idx < out_words) a.out[idx] = word;
+    unsigned char *flag = s_flag[wave];
+    const u32 o = lane >= 31 ? lane - 31 : lane;               // repack shift of this lane's output word
+    const u64 hi_half = 0x3FFFFFFF80000000ull;                 // lanes 31..61 take the groups one lane further up
+    for (u64 seg = k_begin + wave; seg < k_end; seg += kExpandWaves) {
+        const u64 target = seg * kSegGroups - base; // tile-relative position of the segment's first group
+        const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
+        // 64-ary search over the coarse prefix: last 64-word bucket that starts at or before the target
+        const u64 c = lane < kCoarse ? s_coarse[lane] : ~0ull;
+        const u32 bucket = (u32)__popcll(__ballot(c <= target)) - 1u;
+        const u64 drop = target - uniform64(s_coarse[bucket]); // groups of the bucket in front of the segment
+
+        reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+        // mark the first group of every word that contributes to the segment (clipped at the segment start)
+        u32 first_word = 0; // tile-local index of the word that covers the segment's first group
+        bool have_first = false;
+        u64 seen = 0;       // groups of the words looked at so far, from the bucket start
+        u32 wi = bucket * 64u;
+        while (seen < drop + nvalid && tile_w0 + wi < a.c_words) {
+            const u32 idx = wi + lane;
+            const bool in = tile_w0 + idx < a.c_words;
+            const u32 ww = in ? tile_word(s_words, a, tile_w0, idx) : 0u;
+            const u32 n = in ? word_groups(ww) : 0u;
+            bool contributes;
+            u32 p = 0;
+            u64 batch_total;
+            if (__ballot(n > (1u << 20)) == 0 && drop - (seen < drop ? seen : drop) < (1ull << 27)) {
+                // common case: everything fits 32 bits relative to `seen`.  All literals (dense data): the
+                // positions are consecutive, no scan at all; otherwise a DPP scan.
+                const u32 n_in = (u32)__popcll(__ballot(in)); // (ballots must not sit inside a per-lane select)
+                const u32 incl_n = __ballot((int)ww < 0) == 0 ? (in ? lane + 1u : n_in) : wave_scan_incl32(n);
+                const u32 lead = (u32)(drop - (seen < drop ? seen : drop)); // groups still to drop in this batch
+                const u32 past = seen > drop ? (u32)(seen - drop) : 0u;     // segment groups already covered
+                const u32 lo = incl_n - n, hi = incl_n;
+                contributes = n != 0 && hi > lead && lo + past < lead + nvalid;
+                p = (lo > lead ? lo - lead : 0u) + past;
+                batch_total = (u32)__builtin_amdgcn_readlane((int)incl_n, 63);
+            } else {
+                const u64 incl_n = wave_scan_incl((u64)n, lane);
+                const u64 lo = seen + (incl_n - n), hi = seen + incl_n; // the word covers [lo, hi) from the bucket start
+                contributes = n != 0 && hi > drop && lo < drop + nvalid;
+                p = lo > drop ? (u32)(lo - drop) : 0u;
+                batch_total = uniform64(__shfl(incl_n, 63));
+            }
+            if (contributes) flag[p] = 1; // distinct groups: plain byte stores, no atomics
+            const u64 cmask = __ballot(contributes);
+            if (!have_first && cmask) {
+                first_word = uniform32(wi + (u32)__ffsll((long long)cmask) - 1u);
+                have_first = true;
+            }
+            seen += batch_total;
+            wi += 64u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (seen < drop + nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
+            if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+            continue;
+        }
+
+        // expand: group g belongs to the r-th contributing word, r = (marks at positions <= g) - 1
+        const bool whole = nvalid == kSegGroups && (seg + 1) * kSegWords <= out_words; // wave-uniform
+        u32 *const dst = a.out + seg * kSegWords; // wave-uniform base: stores use base + lane*4 + 248*s
+        u32 before = 0;                           // marks in earlier steps
+#pragma unroll
+        for (int s = 0; s < (int)kSteps; ++s) {
+            const u64 m = __ballot(flag[64 * s + (int)lane] != 0); // word starts among this step's 64 groups
+            // inclusive rank - 1 = marks below me + (mark at me) - 1
+            const u32 r = rank_below(m) + (__builtin_amdgcn_inverse_ballot_w64(m) ? 1u : 0u) + (first_word + before - 1u);
+            before += (u32)__popcll(m);
+            u32 src_word;
+            if (first_word + before <= (u32)kScanTileWords) // every word of this step is inside the tile (uniform)
+                src_word = s_words[r];
+            else
+                src_word = tile_word(s_words, a, tile_w0, r);
+            // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354)
+            const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
+            u32 grp = (int)src_word < 0 ? fill_val : src_word;
+            if (!whole && (u32)(64 * s) + lane >= nvalid) grp = 0u;
+
+            // 31 -> 32 repack (mergeWords, kernels.cu:375): output word 62 s + l takes stream bits
+            // [32 (62 s + l), +32) = groups 64 s + l + (l >= 31) and the next one, shifted by l mod 31
+            const u32 g1 = __builtin_amdgcn_update_dpp(0u, grp, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+            const u32 g2 = __builtin_amdgcn_update_dpp(0u, g1, 0x130, 0xf, 0xf, false);
+            const bool up = __builtin_amdgcn_inverse_ballot_w64(hi_half);
+            const u32 a0 = up ? g1 : grp;
+            const u32 a1 = up ? g2 : g1;
+            const u32 word = (a0 >> o) | (a1 << (31u - o));
+            if (whole) {
+                if (lane < 62) dst[62 * s + (int)lane] = word;
+            } else {
+                const u64 idx = seg * kSegWords + 62u * s + lane;
+                if (lane < 62 && idx < out_words) a.out[idx] = word;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 
@@ -911,6 +1153,17 @@ __global__ void gen_clustered_kernel(u32 *out, u64 n, u64 seed, u64 thr) {
 
 __global__ __launch_bounds__(256) void copy_kernel(const uint4 *in, uint4 *out, u64 n16) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (u64)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+// The census counts what was resident at one moment; near the edge that depends on how the dispatcher happened to
+// place the wavefronts (measured: census 1184, runs above ~1060 workgroups lost a workgroup).  Keep a margin: only
+// whole multiples of the CU count are used, i.e. what EVERY compute unit can hold.
+int whole_per_cu(int resident) {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus < 1) cus = 1;
+    return resident >= cus ? (resident / cus) * cus : resident;
 }
 
 int persistent_grid(const void *kernel, int threads, u64 n_tiles) {
@@ -950,6 +1203,7 @@ int compress_grid_for(u32 *d_ctrl, hipStream_t s) {
     }
     if (resident < 1) return -1;
     if (resident > upper) resident = upper;
+    resident = whole_per_cu(resident);
     cached[dev] = resident;
     return resident;
 }
@@ -966,19 +1220,40 @@ hipError_t launch_compress(int workers, const CompressArgs &a, int grid, hipStre
     return hipGetLastError();
 }
 
-int decode_scan_grid(u64 n_tiles) {
-    return persistent_grid(reinterpret_cast<const void *>(&decode_scan_kernel), kScanThreads, n_tiles);
+int decode_sums_grid(u32 *d_ctrl, hipStream_t s) {
+    static int cached[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] > 0) return cached[dev];
+    const int upper = persistent_grid(reinterpret_cast<const void *>(&decode_sums_kernel), (kSumWorkers + 1) * 64, ~0ull);
+    ScanArgs a = {};
+    a.ctrl = d_ctrl;
+    a.census = 1;
+    int resident = 0;
+    if (hipMemsetAsync(d_ctrl, 0, kCtlWords * sizeof(u32), s) == hipSuccess) {
+        hipLaunchKernelGGL(decode_sums_kernel, dim3(upper), dim3((kSumWorkers + 1) * 64), 0, s, a);
+        u32 seen = 0;
+        if (hipGetLastError() == hipSuccess &&
+            hipMemcpyAsync(&seen, d_ctrl + kCtlCensus, sizeof seen, hipMemcpyDeviceToHost, s) == hipSuccess &&
+            hipStreamSynchronize(s) == hipSuccess)
+            resident = (int)seen;
+    }
+    if (resident < 1) return -1;
+    if (resident > upper) resident = upper;
+    resident = whole_per_cu(resident);
+    cached[dev] = resident;
+    return resident;
 }
 
-hipError_t launch_decode_scan(const ScanArgs &a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(decode_scan_kernel, dim3(grid), dim3(kScanThreads), 0, s, a);
+hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(decode_sums_kernel, dim3(grid), dim3((kSumWorkers + 1) * 64), 0, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_decode_expand(const ExpandArgs &a, u64 max_segments, hipStream_t s) {
-    const u64 blocks = (max_segments + kExpandWaves - 1) / kExpandWaves;
-    if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(decode_expand_kernel, dim3((unsigned)blocks), dim3(kExpandWaves * 64), 0, s, a);
+hipError_t launch_decode_expand(const ExpandArgs &a, u64 n_tiles, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    hipLaunchKernelGGL(decode_expand_kernel, dim3((unsigned)n_tiles), dim3(kExpandThreads), 0, s, a);
     return hipGetLastError();
 }
 
