@@ -3,21 +3,22 @@
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-One "step" = one pass of the hot path over one synthetic bitmap resident in HBM:
-compress() followed by decompress() of the result (BASELINE.json configs[1]: 1 GiB
-uniform p = 0.01, round trip on one MI355X).  `value` is uncompressed input bytes per
-second through the whole round trip, aggregated over all ranks; with N > 1 every rank
-works on its own independent column (no collective on the data path -- columns are
-unrelated bitmaps), so scaling is "weak".
+One "step" = one pass of the hot path over synthetic bitmaps already resident in HBM:
+  sparse / clustered / dense : compress() then decompress() of one 1 GiB bitmap
+                               (BASELINE.json configs[1] / [2] / [3]; default: sparse = configs[1])
+  columns                    : compress() of this rank's share of many independent 128 MiB columns
+                               (configs[4]; column c belongs to rank c mod N)
+`value` is uncompressed input bytes per second through the step, whole job: with N > 1 every rank works on its own
+bitmap(s) -- columns are unrelated, there is no collective on the data path -- so scaling is "weak" (fixed work per
+GPU); the time is the maximum over ranks of a barrier-bracketed wall clock.
 
 The JSON line also carries
-  roofline     : the dominant kernel (compress) against the HBM roof.  achieved =
-                 algorithmic bytes (4N + 4C) / average launch duration,
-                 measured here with device events on the stream the kernel runs on.
-  cpu_baseline : the CPU oracle (a port of the reference algorithm; the reference has
-                 no CPU path and its CUDA cannot run here) timed on a bounded sample of
-                 the same workload on this box's host cores.
-Other workloads (--workload clustered|dense|sparse) are the remaining BASELINE configs.
+  roofline     : the dominant kernel (compress_kernel) against the HBM roof.  achieved = algorithmic bytes per launch
+                 (4N + 4C) / its average launch duration, measured here with device events on the
+                 stream it runs on.  `traffic` = HBM bytes per launch from the PMC passes recorded in
+                 profiles/traffic.json (rocprofv3 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes + WRITE_SIZE).
+  cpu_baseline : the CPU oracle (a port of the reference algorithm -- the reference has no CPU path and its CUDA
+                 cannot run here) timed on a bounded sample of the same workload on this box's host cores.
 """
 import argparse
 import importlib
@@ -36,7 +37,9 @@ WORKLOADS = {
     # name: (generator, parameter, description)
     "sparse": ("uniform", 0.01, "1 GiB uniform p=0.01 bitmap, compress+decompress round trip (BASELINE configs[1])"),
     "clustered": ("clustered", 4096, "1 GiB clustered runs (mean 4096 bits), compress+decompress (BASELINE configs[2])"),
-    "dense": ("uniform", 0.5, "1 GiB uniform p=0.5 bitmap, all literals (BASELINE configs[3])"),
+    "dense": ("uniform", 0.5, "1 GiB uniform p=0.5 bitmap, all literals, compress+decompress (BASELINE configs[3])"),
+    "columns": (None, None, "independent 128 MiB bitmap columns (sparse/clustered/dense in turn), compress, column c on "
+                            "rank c mod N (BASELINE configs[4])"),
 }
 
 
@@ -46,17 +49,43 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="sparse", choices=sorted(WORKLOADS))
-    ap.add_argument("--words", type=int, default=268435200, help="bitmap size in 32-bit words (default: 270600 whole segments = 1 GiB - 256 words)")
+    ap.add_argument("--words", type=int, default=None,
+                    help="bitmap size in 32-bit words (default 268435200 = 270600 whole segments = 1 GiB - 1 KiB; "
+                         "columns: 33554400 = 128 MiB)")
+    ap.add_argument("--columns", type=int, default=None, help="columns workload: total number of columns (default 64 per GPU)")
     ap.add_argument("--cpu-sample-mib", type=int, default=256, help="size of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1337)
     return ap.parse_args()
 
 
-def make_input(wah, kind, param, n, seed):
-    if kind == "uniform":
-        return wah.gen_uniform_device(n, seed, param)
-    return wah.gen_clustered_device(n, seed, param)
+def timed_steps(step, steps, warmup, dist=None, device=None):
+    """The measurement contract: W untimed steps, then exactly K steps between two barriers (+ device syncs), and
+    the MAX over ranks of the wall time.  `dist` is torch.distributed (or None), `device` a CUDA device (or None on
+    the CPU rehearsal)."""
+    import torch
+
+    def barrier():
+        if device is not None:
+            torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+        if device is not None:
+            torch.cuda.synchronize(device)
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
 
 
 def cpu_baseline(kind, param, sample_mib, seed):
@@ -81,6 +110,14 @@ def cpu_baseline(kind, param, sample_mib, seed):
     return res
 
 
+def load_traffic(workload):
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get(workload)
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     import torch
@@ -91,20 +128,59 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
+    dev = torch.device(f"cuda:{local_rank}")
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     wah = importlib.import_module("gpu-wah_amd")
     wah.lib()
-
     kind, param, desc = WORKLOADS[args.workload]
-    n = args.words
-    d_in = make_input(wah, kind, param, n, args.seed + rank)  # every rank: its own column
+
+    if args.workload == "columns":
+        n = args.words or 33554400
+        n_columns = args.columns or 64 * world
+        mine = wah.columns.shard_columns(n_columns, rank, world)
+        cols = [wah.columns.make_column(wah, wah.columns.column_spec(c, n, args.seed), dev) for c in mine]
+        comp = wah.DeviceCompressor(n, device=dev)
+        sizes = []
+
+        def step():
+            sizes[:] = wah.columns.compress_columns(comp, cols)
+
+        step()
+        comp.status()
+        c_words_rank = float(sum(int(s.item()) for s in sizes))
+        elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
+        comp.status()
+        stats = torch.tensor([4.0 * n * len(cols), c_words_rank], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(stats)
+        if rank == 0:
+            in_bytes_job, c_words_job = float(stats[0].item()), float(stats[1].item())
+            out = {
+                "metric": "compress GB/s (input bits), independent 128 MiB bitmap columns",
+                "value": round(args.steps * in_bytes_job / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                "config": {"workload": desc, "words_per_column": n, "columns": n_columns,
+                           "columns_per_gpu": len(cols), "seed": args.seed,
+                           "parallelism": f"column-shard x{world}, no collective"},
+                "compression_ratio_C_over_N": round(c_words_job * 4.0 / in_bytes_job, 6),
+            }
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- single bitmap per GPU: compress + decompress round trip ---------------------------------------------
+    n = args.words or 268435200
+    d_in = (wah.gen_uniform_device(n, args.seed + rank, param, device=dev) if kind == "uniform"
+            else wah.gen_clustered_device(n, args.seed + rank, param, device=dev))  # every rank: its own bitmap
     comp = wah.DeviceCompressor(n, device=dev)
     comp.run(d_in)
     c_words = comp.result().numel()
@@ -112,45 +188,27 @@ def main():
     dec.run(comp.out)
     assert torch.equal(dec.result()[:n], d_in), "round trip mismatch"
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    events = []
 
-    def step(ev=None):
-        if ev:
-            ev[0].record()
+    def step():
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
         comp.run(d_in)
-        if ev:
-            ev[1].record()
+        ev[1].record()
         dec.run(comp.out, c_words)
-        if ev:
-            ev[2].record()
+        ev[2].record()
+        events.append(ev)
 
-    for _ in range(args.warmup):
-        step()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for ev in events:
-        step(ev)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
     comp.status()
     dec.status()
-
-    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    elapsed = float(t_all.item())
-
-    comp_ms = sorted(e[0].elapsed_time(e[1]) for e in events)
-    dec_ms = sorted(e[1].elapsed_time(e[2]) for e in events)
+    timed = events[args.warmup:]
+    comp_ms = sorted(e[0].elapsed_time(e[1]) for e in timed)
+    dec_ms = sorted(e[1].elapsed_time(e[2]) for e in timed)
     comp_avg = sum(comp_ms) / len(comp_ms)
     dec_avg = sum(dec_ms) / len(dec_ms)
 
-    # on-box copy ceiling: 16 B/lane copy of the same 1 GiB (read + write)
+    # on-box copy ceiling: 16 B/lane copy of the same bitmap (read + write)
     scratch = torch.empty_like(d_in)
     for _ in range(2):
         wah.copy_device(d_in, scratch)
@@ -165,23 +223,19 @@ def main():
 
     if rank == 0:
         in_bytes = 4.0 * n
-        algo_c = 4.0 * n + 4.0 * c_words                       # compress: read N, write C
-        algo_d = 4.0 * c_words + 4.0 * ((31 * ((32 * n + 30) // 31) + 31) // 32)  # decompress: read C, write N'
+        groups = (32 * n + 30) // 31
+        algo_c = 4.0 * n + 4.0 * c_words                          # compress: read N, write C
+        algo_d = 4.0 * c_words + 4.0 * ((31 * groups + 31) // 32)  # decompress: read C, write N'
         achieved = algo_c / (comp_avg * 1e-3) / 1e9
+        achieved_d = algo_d / (dec_avg * 1e-3) / 1e9
+        tr = load_traffic(args.workload) or {}
         out = {
             "metric": "compress+decompress GB/s (input bits), 1 GiB bitmap",
             "value": round(world * args.steps * in_bytes / elapsed / 1e9, 3),
-            "unit": "GB/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
+            "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": desc, "words": n, "seed": args.seed, "columns_per_gpu": 1,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": desc, "words": n, "seed": args.seed, "bitmaps_per_gpu": 1,
                        "parallelism": f"column-shard x{world}, no collective"},
             "compression_ratio_C_over_N": round(c_words / n, 6),
             "compress_GBps": round(in_bytes / (comp_avg * 1e-3) / 1e9, 2),
@@ -189,24 +243,17 @@ def main():
             "compress_ms": {"avg": round(comp_avg, 4), "min": round(comp_ms[0], 4), "median": round(comp_ms[len(comp_ms) // 2], 4)},
             "decompress_ms": {"avg": round(dec_avg, 4), "min": round(dec_ms[0], 4), "median": round(dec_ms[len(dec_ms) // 2], 4)},
             "copy_ceiling_GBps": round(copy_gbps, 1),
-            "roofline": {"kernel": "compress_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": algo_c, "frac_of_copy_ceiling": round(achieved / copy_gbps, 4)},
-            "roofline_decompress": {"kernel": "decode_scan_kernel+decode_expand_kernel", "bound": "hbm",
-                                    "achieved": round(algo_d / (dec_avg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
-                                    "unit": "GB/s", "frac": round(algo_d / (dec_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                    "traffic": None, "algorithmic_bytes_per_launch": algo_d},
+            "roofline": {"kernel": "compress_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                         "traffic": tr.get("compress_bytes_per_launch"), "traffic_source": tr.get("source"),
+                         "algorithmic_bytes_per_launch": algo_c, "launch_ms": round(comp_avg, 4),
+                         "frac_of_copy_ceiling": round(achieved / copy_gbps, 4)},
+            "roofline_decompress": {"kernel": "decode_sums_kernel + decode_expand_kernel", "bound": "hbm",
+                                    "achieved": round(achieved_d, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "frac": round(achieved_d / HBM_PEAK_GBPS, 4),
+                                    "traffic": tr.get("decompress_bytes_per_launch"),
+                                    "algorithmic_bytes_per_launch": algo_d, "launch_ms": round(dec_avg, 4)},
         }
-        traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                tr = json.load(open(traffic_file)).get(args.workload)
-                if tr:
-                    out["roofline"]["traffic"] = tr.get("compress_bytes_per_launch")
-                    out["roofline"]["traffic_source"] = tr.get("source")
-                    out["roofline_decompress"]["traffic"] = tr.get("decompress_bytes_per_launch")
-            except Exception:
-                pass
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, param, args.cpu_sample_mib, args.seed)
         print(json.dumps(out), flush=True)

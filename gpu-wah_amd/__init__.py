@@ -17,6 +17,7 @@ The directory name contains a hyphen, so import it with
     importlib.import_module("gpu-wah_amd")
 or through the `gpu_wah_amd` shim module at the repository root.
 """
+from . import columns  # noqa: F401
 from .api import (  # noqa: F401
     WahError,
     Timings,

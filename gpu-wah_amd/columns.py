@@ -1,0 +1,51 @@
+"""Column sharding for many independent bitmaps (BASELINE.json configs[4]).
+
+Bitmap columns are unrelated, so a node with N GPUs is N independent compressors: column c belongs to rank
+c mod N, every rank walks its own columns on its own device and streams, and the only cross-rank step is
+adding up byte counts and taking the slowest rank's time.  No collective touches bitmap data.
+
+The reference has no multi-device code at all (single device, default stream: compress.cu:129,166); this
+module is the "many columns" driver a caller of the reference would have written around compress().
+"""
+from collections import namedtuple
+
+ColumnSpec = namedtuple("ColumnSpec", "index kind seed n_words")
+
+KINDS = ("sparse", "clustered", "dense")  # uniform p=0.01 / runs of mean 4096 bits / uniform p=0.5
+
+
+def shard_columns(n_columns, rank, world):
+    """Indices of the columns rank `rank` of `world` owns: c with c % world == rank (round robin)."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    return list(range(rank, n_columns, world))
+
+
+def column_spec(index, n_words, seed=1337):
+    """Deterministic description of synthetic column `index`: the three bench distributions in turn."""
+    return ColumnSpec(index, KINDS[index % len(KINDS)], seed + index, n_words)
+
+
+def make_column(wah, spec, device):
+    """Generate the column in HBM on `device` (bit-exact definition: include/wah_gen.h)."""
+    if spec.kind == "sparse":
+        return wah.gen_uniform_device(spec.n_words, spec.seed, 0.01, device=device)
+    if spec.kind == "dense":
+        return wah.gen_uniform_device(spec.n_words, spec.seed, 0.5, device=device)
+    return wah.gen_clustered_device(spec.n_words, spec.seed, 4096, device=device)
+
+
+def compress_columns(compressor, columns):
+    """Enqueue one compress pass per column on the current stream; returns the list of compressed sizes
+    (device tensors, read them after synchronising).  The compressor's output buffer is reused, so callers
+    that need the words copy them out between columns."""
+    sizes = []
+    for col in columns:
+        compressor.run(col)
+        sizes.append(compressor.count.clone())
+    return sizes
+
+
+def aggregate_throughput(bytes_per_rank, seconds_per_rank):
+    """Whole-job rate: all bytes / the slowest rank's time (what bench.py reports for N > 1)."""
+    return sum(bytes_per_rank) / max(seconds_per_rank)

@@ -20,21 +20,13 @@ constexpr uint32_t kSegGroups = 1024;
 constexpr uint32_t kSteps = 16; // 64 groups (one wavefront) per step
 
 // ---- inter-workgroup control block (uint32 words, zeroed before each launch)
-constexpr uint32_t kShards = 8;          // tile-ticket counters
-constexpr uint32_t kCtlStart = 0;        // arrival ticket -> virtual workgroup id
-constexpr uint32_t kCtlShard0 = 16;      // shard i at kCtlShard0 + 16*i (own 64-B line)
+constexpr uint32_t kCtlStart = 0;        // arrival ticket: order in which workgroups start running
 constexpr uint32_t kCtlError = 160;      // sticky error bits
 constexpr uint32_t kCtlCensus = 161;     // census mode: workgroups resident together
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
-constexpr uint32_t kErrTimeout = 1u;     // a bounded look-back spin expired
+constexpr uint32_t kErrTimeout = 1u;     // a bounded wait expired
 constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity
 constexpr uint32_t kErrStream = 4u;      // malformed compressed stream
-
-// ---- tile descriptor of the decoupled look-back: {status:2, value:62} -----
-constexpr unsigned kStatusShift = 62;
-constexpr uint64_t kStatusAggregate = 1ull << kStatusShift;
-constexpr uint64_t kStatusPrefix = 2ull << kStatusShift;
-constexpr uint64_t kValueMask = (1ull << kStatusShift) - 1;
 
 // ---- compress geometry: one wavefront owns one segment --------------------
 // worker wavefronts = segments per tile: 7 (+1 scan wave = 512 threads, 2 workgroups per CU) or

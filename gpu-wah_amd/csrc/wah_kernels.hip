@@ -1,27 +1,22 @@
 // wah_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the WAH path.
 //
-// What the reference does in five kernels, two thrust scans and four blocking
-// 8-byte D2H copies (compress.cu:129-166, decompress.cu:66-115, kernels.cu),
-// is done here in
-//   compress   : ONE persistent kernel  (read 4N, write 4C, nothing else)
-//   decompress : scan kernel + expand kernel
-// built on three CDNA4 idioms:
-//   * a wavefront (64 lanes) owns a whole 1024-group segment; the segment's 992
-//     words are staged once in wave-private LDS with 16-byte coalesced loads and
-//     re-read as 31-bit groups by a funnel shift (v_alignbit) -- the regroup of
-//     kernels.cu:72-79 without 1/32 idle lanes and without the shift-by-32;
-//   * zero/ones classification produces 64-bit lane masks straight from v_cmp
-//     (ballot), so run detection (kernels.cu:126-149), run lengths (:156-174)
-//     and the cross-warp merge (:188-229) collapse into a few SCALAR mask
-//     operations per 64 groups plus one mbcnt rank per lane;
-//   * output offsets come from a single-pass decoupled look-back over per-tile
-//     descriptors (one 8-byte {status,value} granule per tile, written and
-//     polled with agent-scope relaxed atomics: correct across the 8 non-coherent
-//     XCD L2s) instead of thrust::exclusive_scan + moveData
-//     (compress.cu:133-166, kernels.cu:273-280).
-// Tiles are handed out by sharded arrival tickets, so forward progress never
-// depends on dispatch order or on all workgroups being co-resident, and every
-// spin is bounded.
+// What the reference does in five kernels, two thrust scans and four blocking 8-byte D2H copies
+// (compress.cu:129-166, decompress.cu:66-115, kernels.cu), is done here in
+//   compress   : ONE persistent kernel            (reads 4N, writes 4C, nothing else)
+//   decompress : streaming sums kernel + expand   (reads 4C twice, writes 4N')
+// built on these CDNA4 idioms:
+//   * a wavefront (64 lanes) owns a whole 1024-group segment; its 992 words are staged once in wave-private LDS
+//     with 16-byte coalesced loads and re-read as 31-bit groups by a funnel shift (v_alignbit) -- the regroup of
+//     kernels.cu:72-79 without idle lanes and without the shift-by-32;
+//   * zero/ones classification produces 64-lane masks straight from v_cmp, "same as the next group" is one DPP
+//     compare, so run detection, run lengths and the cross-warp merge (kernels.cu:126-229) collapse into a couple
+//     of scalar mask operations per 64 groups plus one v_mbcnt rank per lane;
+//   * run-end words are compacted in LDS and leave the chip as dense 256-byte stores;
+//   * output offsets come from a one-hop "generation scan" over 4-byte {valid,count} granules written and polled
+//     with agent-scope relaxed atomics (correct across the 8 non-coherent XCD L2s), instead of
+//     thrust::exclusive_scan + moveData (compress.cu:133-166, kernels.cu:273-280);
+//   * tiles are assigned round robin to the workgroups in arrival order, the grid is sized from a residency census
+//     of the kernel itself, and every wait is bounded: a lost workgroup ends in WAH_ERR_TIMEOUT, never in a hang.
 #include "wah_internal.hpp"
 
 #include "../../include/wah_gen.h"
@@ -53,19 +48,11 @@ using u64 = uint64_t;
 #define WAH_STAMP_FLUSH(ctrl)
 #endif
 
-constexpr u32 kSegLdsWords = 1008;  // 992 + 1 look-ahead word, padded to a multiple of 16 bytes
 constexpr u32 kMaxSpins = 1u << 21; // bounded look-back wait
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 // wave-uniform by construction; readfirstlane tells the compiler so (keeps masks and offsets in SGPRs)
 __device__ __forceinline__ u32 wave_id() { return (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-
-__device__ __forceinline__ u64 desc_load(const u64 *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void desc_store(u64 *p, u64 v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 __device__ __forceinline__ u64 wave_sum(u64 v) {
 #pragma unroll
@@ -113,113 +100,11 @@ __device__ __forceinline__ u32 rank_below(u64 m) {
     return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
 }
 
-// ---------------------------------------------------------------------------
-// Tile tickets.  A workgroup first draws an arrival ticket (its virtual id),
-// which fixes its shard; it then draws tile numbers j from that shard's counter
-// and processes tile j*kShards + shard.  Tiles of one shard are handed out in
-// increasing order to running workgroups, and the first kShards arrivals cover
-// all shards, so the lowest unfinished tile is always held by (or next in line
-// for) a running workgroup: the look-back below cannot deadlock, whatever the
-// dispatch order or residency.
-// ---------------------------------------------------------------------------
+// Arrival ticket: the order in which workgroups actually start running.  Tiles are dealt round robin in THIS
+// order (never in blockIdx order, which says nothing about dispatch), so a workgroup only ever waits for
+// workgroups that are already running.
 __device__ __forceinline__ u32 draw_arrival(u32 *ctrl) {
     return __hip_atomic_fetch_add(ctrl + kCtlStart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// (tile numbers are 32-bit: hosts reject inputs with 2^31 tiles or more; a shard counter that runs past the
-//  end only ever yields numbers >= n_tiles because every workgroup stops at its first such ticket)
-__device__ __forceinline__ u32 draw_tile(u32 *ctrl, u32 shard) {
-    const u32 j = __hip_atomic_fetch_add(ctrl + kCtlShard0 + 16u * shard, 1u, __ATOMIC_RELAXED,
-                                         __HIP_MEMORY_SCOPE_AGENT);
-    return j * kShards + shard;
-}
-
-// ---------------------------------------------------------------------------
-// Two-level decoupled look-back, executed by one full wavefront in ONE round trip.
-//
-// A flat look-back advances its "prefix frontier" by one window (64 tiles) per poll round trip, which caps the
-// whole kernel at window * tile_bytes / poll_latency (measured: the look-back was 45 % of a tile's lifetime).
-// Here tiles are grouped into blocks of 32:
-//   tile  descriptor t : {AGGREGATE, words of tile t}                     -- one store per tile
-//   block descriptor b : {AGGREGATE, words of block b} then {PREFIX, words of blocks 0..b}
-// One 64-lane poll reads, side by side,
-//   lanes  0..31 : the earlier tiles of my own block          (all must be published)
-//   lanes 32..63 : the 32 blocks in front of mine             (up to the nearest PREFIX)
-// so the frontier moves 32 blocks = 1024 tiles per round trip, and a tile needs no PREFIX status at all.
-// The block descriptors are written by the block's LAST tile (index 31), which sees every tile aggregate of the
-// block in its own poll anyway -- no atomics.  Descriptors are single 8-byte granules written and read with
-// agent-scope relaxed atomics (sc1): the data IS the flag, correct across the 8 non-coherent XCD L2s.
-// ---------------------------------------------------------------------------
-constexpr u32 kBlockTiles = 32;
-
-__device__ __forceinline__ u64 resolve_tile_prefix(u64 *tile_desc, u64 *block_desc, u64 tile, u64 aggregate, u32 lane,
-                                                   u32 *ctrl) {
-    const u64 blk = tile / kBlockTiles;
-    const u32 j = (u32)(tile % kBlockTiles);
-    if (lane == 0) desc_store(tile_desc + tile, kStatusAggregate | aggregate);
-
-    const bool tile_lane = lane < 32;
-    const u32 k = lane - 32; // block lanes: distance (in blocks) behind the newest block of the window
-    bool have_intra = (j == 0), have_blocks = (blk == 0);
-    bool block_aggregate_published = false;
-    u64 intra = 0, before = 0;
-    long long newest = (long long)blk - 1; // newest block of the current block-level window
-    u32 spins = 0;
-
-    while (!(have_intra && have_blocks)) {
-        u64 d = 0;
-        if (tile_lane) {
-            if (!have_intra && lane < j) d = desc_load(tile_desc + blk * kBlockTiles + lane);
-        } else if (!have_blocks) {
-            const long long bb = newest - (long long)k;
-            d = bb >= 0 ? desc_load(block_desc + bb) : kStatusPrefix; // virtual "prefix 0" in front of block 0
-        }
-        const u32 st = (u32)(d >> kStatusShift);
-        const u64 val = d & kValueMask;
-        bool progressed = false;
-
-        if (!have_intra) {
-            const u64 missing = __ballot(tile_lane && lane < j && st == 0u);
-            if (missing == 0) {
-                intra = uniform64(wave_sum((tile_lane && lane < j) ? val : 0ull));
-                have_intra = true;
-                progressed = true;
-            }
-        }
-        // the block's last tile knows the block aggregate as soon as its intra-block poll is complete:
-        // publish it at once so later blocks never wait for this tile's own block-level resolution
-        if (have_intra && j == kBlockTiles - 1 && !block_aggregate_published) {
-            if (lane == 0) desc_store(block_desc + blk, kStatusAggregate | (intra + aggregate));
-            block_aggregate_published = true;
-        }
-        if (!have_blocks) {
-            const u32 invalid = (u32)(__ballot(!tile_lane && st == 0u) >> 32);
-            const u32 prefix = (u32)(__ballot(!tile_lane && st == 2u) >> 32);
-            if (prefix) {
-                const u32 first = (u32)__ffs((int)prefix) - 1u; // nearest block with a full prefix
-                if ((invalid & ((1u << first) - 1u)) == 0) {
-                    before += uniform64(wave_sum((!tile_lane && k <= first) ? val : 0ull));
-                    have_blocks = true;
-                    progressed = true;
-                }
-            } else if (invalid == 0) { // 32 block aggregates and no prefix yet: keep walking back
-                before += uniform64(wave_sum(!tile_lane ? val : 0ull));
-                newest -= 32;
-                progressed = true;
-            }
-        }
-        if (!progressed) {
-            if (++spins > kMaxSpins) {
-                if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        } else {
-            spins = 0;
-        }
-    }
-    const u64 excl = before + intra;
-    if (j == kBlockTiles - 1 && lane == 0) desc_store(block_desc + blk, kStatusPrefix | (excl + aggregate));
-    return excl;
 }
 
 // ---------------------------------------------------------------------------
