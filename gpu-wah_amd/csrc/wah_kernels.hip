@@ -212,6 +212,7 @@ __device__ __forceinline__ u64 resolve_generation(const u32 *gdesc, u32 gen, u32
 // whole iteration late, instead of every generation waiting for its slowest member.
 // ===========================================================================
 constexpr u32 kStageWords = 1024; // staged segment (992 words + look-ahead) / compacted output words (<= 1024), aliased
+constexpr u32 kOutWords = kStageWords + 4; // + one dump dword (non-end lanes), kept 16-byte aligned
 constexpr u32 kPosEntries = 1032; // pos[0] = -1 sentinel, pos[k+1] = group position of run end k (u16)
 
 struct Prefetch {
@@ -259,6 +260,16 @@ __device__ __forceinline__ void stage_slow(const CompressArgs &a, u32 seg, u32 *
 //             (rank < 64 s <= 62 (s+1), the lowest word still to be read), with the group position beside it
 //             (fill lengths are position differences, see the emit loop).
 // kFull = all 1024 groups exist (every segment but possibly the last one of the bitmap).
+// v_bcnt_u32_b32: acc + popcount(mask half).  Spelled out because the compiler would do a uniform popcount on the
+// scalar unit -- and on CDNA4 a SIMD gets one scalar instruction per ~4 cycles (the scalar ALU is shared by the CU's
+// four SIMDs; measured) against one vector instruction per ~2.5.  The inner loop below therefore keeps even its
+// wave-uniform bookkeeping (the running word count) in a vector register and issues no scalar ALU work at all.
+__device__ __forceinline__ u32 add_popcount(u32 acc, u64 mask) {
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "s"((u32)mask));
+    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "s"((u32)(mask >> 32)));
+    return acc;
+}
+
 template <bool kFull>
 __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigned short *pos, u32 r, u32 lane_v,
                                                 u32 nvalid, bool &any_fill) {
@@ -274,42 +285,46 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
     x[kSteps] = 0xFFFFFFFFu; // "group after the last one": a value no 31-bit group can equal
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
-    // phase 2: straight-line, one block per step (no data-dependent branches, so the 16 short dependency chains
-    // can be interleaved by the scheduler):
-    //   fill  = 1 v_sub + 1 v_cmp   : x - 1 >= 0x7FFFFFFE (unsigned)  <=>  x is 0 or 0x7FFFFFFF
-    //   same  = DPP move + v_cmp    : value of the next group (lane 63: `old` operand = lane 0 of the next step)
-    //   ends  = ~(fill & same)      : 1 scalar op
-    //   rank  = v_mbcnt pair seeded with the running count (scalar)
-    u32 count = 0;
-    u64 fill_ends = 0;
+    // phase 2: one straight-line block of vector instructions per step.
+    //   next   : value of the following group = lane l+1 (DPP wave_shl:1); lane 63 has no source lane and keeps the
+    //            `old` operand, which a wave_rol:1 of the NEXT step's register has loaded with that step's lane 0
+    //   z      : (x ^ next) | ((x + 1) & 0x7FFFFFFE) is zero  <=>  x is 0 or 0x7FFFFFFF AND the next group equals it
+    //            <=>  the group does NOT end a run (kernels.cu:93-141 and the merge of :188-229 in three operations)
+    //   ends   : v_cmp_ne z, 0 -- the 64-lane mask comes out of the compare itself
+    //   rank   : v_mbcnt pair seeded with the running count; count += v_bcnt pair
+    //   write  : every lane stores; lanes that end no run store to a dump slot (cheaper than masking EXEC, which
+    //            is scalar work)
+    u32 count_v = 0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(count_v)); // a VECTOR zero: keeps the running count off the scalar unit
+    u32 min_t = 0xFFFFFFFFu;
+    u32 *const val_dump = lds + kStageWords; // one spare dword behind the buffer
+    unsigned short *const pos_dump = pos + (kPosEntries - 2);
 #pragma unroll
     for (int s = 0; s < (int)kSteps; ++s) {
-        u64 fill = __ballot(x[s] - 1u >= 0x7FFFFFFEu);
-        const u32 first_of_next = (u32)__builtin_amdgcn_readfirstlane((int)x[s + 1]);
-        const u32 nxt = __builtin_amdgcn_update_dpp(first_of_next, x[s], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        u64 same = __ballot(nxt == x[s]);
-        u64 e;
-        if (kFull) {
-            e = ~(fill & same);
-        } else {
+        const u32 carry = __builtin_amdgcn_update_dpp(0u, x[s + 1], 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+        const u32 nxt = __builtin_amdgcn_update_dpp(carry, x[s], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        const u32 t = (x[s] + 1u) & 0x7FFFFFFEu; // zero <=> x is all zeros or all ones
+        const u32 z = (x[s] ^ nxt) | t;
+        u64 e = __ballot(z != 0u);
+        if (!kFull) {
             const int rem = (int)nvalid - 64 * s;
             const u64 valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-            const u64 next_valid = rem - 64 >= 1 ? 1ull : 0ull; // does group 64 (s+1) exist?
-            fill &= valid;
-            same &= (next_valid << 63) | (valid >> 1); // the successor must exist
-            e = valid & ~(fill & same);
+            const u64 last = (rem >= 1 && rem <= 64) ? (1ull << (rem - 1)) : 0ull; // the last existing group closes its run
+            e = (e | last) & valid;
+            if (rem > 0) min_t = min(min_t, (lane_v < (u32)rem) ? t : 0xFFFFFFFFu);
+        } else {
+            min_t = min(min_t, t);
         }
-        fill_ends |= e & fill;
-        if (__builtin_amdgcn_inverse_ballot_w64(e)) {
-            // running count folded into the (scalar) base address: rank*4 + (lds + count), one v_lshl_add each
-            const u32 rank = rank_below(e);
-            (lds + count)[rank] = x[s];
-            (pos + count + 1)[rank] = (unsigned short)(64 * s + (int)lane_v);
-        }
-        count += (u32)__popcll(e);
+        const bool is_end = __builtin_amdgcn_inverse_ballot_w64(e);
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(e >> 32), __builtin_amdgcn_mbcnt_lo((u32)e, count_v));
+        u32 *const vdst = is_end ? lds + rank : val_dump;
+        unsigned short *const pdst = is_end ? pos + rank + 1 : pos_dump;
+        *vdst = x[s];
+        *pdst = (unsigned short)(64 * s + (int)lane_v);
+        count_v = add_popcount(count_v, e);
     }
-    any_fill = fill_ends != 0;
-    return count;
+    any_fill = __ballot(min_t == 0u) != 0; // some group is a fill, so some emitted word is one
+    return uniform32(count_v);
 }
 
 // Tile assignment is a static round robin over the workgroups in ARRIVAL order: the workgroup that draws arrival
@@ -378,7 +393,7 @@ __device__ __forceinline__ bool lds_wait_reached(const u32 *counter, u32 value, 
 
 template <int W>
 __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 s_out[2][W][kStageWords];
+    __shared__ __attribute__((aligned(16))) u32 s_out[2][W][kOutWords];
     __shared__ unsigned short s_pos[W][kPosEntries];
     __shared__ u32 s_count[4][W];    // words per worker of tile (gen & 3)
     __shared__ u32 s_arrived[4];     // workers that have delivered their count for tile (gen & 3)
