@@ -44,7 +44,7 @@ struct CompressArgs {
     uint64_t n_words;
     uint32_t n_segments;          // ceil(G / 1024)
     uint32_t n_tiles;             // ceil(n_segments / kCompressWaves)
-    uint32_t fast_segments;       // segments that lie wholly inside a 16-byte aligned input (prefetch path)
+    uint32_t fast_segments;       // 1: input 16-byte aligned -> prefetched buffer loads; 0: scalar staging
     uint32_t last_segment_groups; // groups of the last segment (1..1024)
     uint32_t *out;
     uint64_t out_capacity;

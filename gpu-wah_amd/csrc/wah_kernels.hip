@@ -215,29 +215,42 @@ constexpr u32 kStageWords = 1024; // staged segment (992 words + look-ahead) / c
 constexpr u32 kOutWords = kStageWords + 4; // + one dump dword (non-end lanes), kept 16-byte aligned
 constexpr u32 kPosEntries = 1032; // pos[0] = -1 sentinel, pos[k+1] = group position of run end k (u16)
 
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
 struct Prefetch {
-    uint4 v[4];
+    u32x4 v[4];
 };
 
-// issue the four coalesced 16-byte loads of one whole segment (3968 B = 248 x 16 B)
-__device__ __forceinline__ void prefetch_segment(const u32 *in, u32 seg, u32 lane, Prefetch &p) {
-    const uint4 *src = reinterpret_cast<const uint4 *>(in + (u64)seg * kSegWords);
-    p.v[0] = src[lane];
-    p.v[1] = src[lane + 64];
-    p.v[2] = src[lane + 128];
-    p.v[3] = src[lane < 56 ? lane + 192 : 247];
+// Buffer descriptor over `bytes` bytes at p (raw, stride 0): loads past the end return 0, stores past the end are
+// dropped -- the hardware does the tail padding (F5) and the capacity clipping, and addresses become
+// descriptor + 32-bit lane offset + immediate, with no 64-bit vector arithmetic per access.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, u32 bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x27000);
 }
 
+// issue the four coalesced 16-byte loads of one segment (3968 B = 248 x 16 B; lanes 56..63 of the fourth load and
+// everything past the end of the bitmap read as zero)
+__device__ __forceinline__ void prefetch_segment(const CompressArgs &a, u32 seg, u32 lane, Prefetch &p) {
+    const u64 w0 = (u64)seg * kSegWords;
+    const u64 left = a.n_words > w0 ? a.n_words - w0 : 0;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.in + w0, left < kSegWords ? (u32)left * 4u : kSegWords * 4u);
+    const u32 off = lane * 16u;
+    p.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    p.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 1024u, 0, 0);
+    p.v[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 2048u, 0, 0);
+    p.v[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 3072u, 0, 0);
+}
+
+// the fourth store also zeroes word 992, the look-ahead word of the last group (and the unused words up to 1023)
 __device__ __forceinline__ void stage_prefetched(const Prefetch &p, u32 *lds, u32 lane) {
-    uint4 *dst = reinterpret_cast<uint4 *>(lds);
+    u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
     dst[lane] = p.v[0];
     dst[lane + 64] = p.v[1];
     dst[lane + 128] = p.v[2];
-    if (lane < 56) dst[lane + 192] = p.v[3];
-    if (lane == 0) lds[kSegWords] = 0u; // look-ahead word of the last group (masked out by the 31-bit mask)
+    dst[lane + 192] = p.v[3];
 }
 
-// tail segment or 4-byte aligned input: bounds-checked scalar staging, zero padded (F5)
+// input that is only 4-byte aligned: bounds-checked scalar staging, zero padded (F5)
 __device__ __forceinline__ void stage_slow(const CompressArgs &a, u32 seg, u32 *lds, u32 lane) {
     const u64 w0 = (u64)seg * kSegWords;
     const u64 left = a.n_words - w0;
@@ -396,6 +409,7 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
     __shared__ __attribute__((aligned(16))) u32 s_out[2][W][kOutWords];
     __shared__ unsigned short s_pos[W][kPosEntries];
     __shared__ u32 s_count[4][W];    // words per worker of tile (gen & 3)
+    __shared__ u32 s_prefix[4][W];   // ... and the words of the workers before it
     __shared__ u32 s_arrived[4];     // workers that have delivered their count for tile (gen & 3)
     __shared__ u32 s_total[4];       // words of tile (gen & 3) ...
     __shared__ u32 s_total_flag[4];  // ... valid when == gen + 1
@@ -485,12 +499,13 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
     unsigned short *const pos = s_pos[wave];
 
     Prefetch pre;
-    pre.v[0] = pre.v[1] = pre.v[2] = pre.v[3] = make_uint4(0, 0, 0, 0);
-    bool pre_valid = false; // wave-uniform: `pre` holds the current tile's segment
+    pre.v[0] = pre.v[1] = pre.v[2] = pre.v[3] = u32x4{0, 0, 0, 0};
+    // wave-uniform: `pre` holds the current tile's segment (always, unless the input is only 4-byte aligned)
+    bool pre_valid = false;
     {
         const u32 seg = arrival * W + wave;
-        if (arrival < a.n_tiles && seg < a.fast_segments) {
-            prefetch_segment(a.in, seg, lane, pre);
+        if (arrival < a.n_tiles && seg < a.n_segments && a.fast_segments) {
+            prefetch_segment(a, seg, lane, pre);
             pre_valid = true;
         }
     }
@@ -527,8 +542,8 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
             {
                 const u32 next_tile = tile + stride;
                 const u32 nseg = next_tile * W + wave;
-                pre_valid = next_tile < a.n_tiles && nseg < a.fast_segments;
-                if (pre_valid) prefetch_segment(a.in, nseg, lane, pre);
+                pre_valid = next_tile < a.n_tiles && nseg < a.n_segments && a.fast_segments;
+                if (pre_valid) prefetch_segment(a, nseg, lane, pre);
             }
 
             const bool has_seg = seg < a.n_segments;
@@ -544,23 +559,29 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
                 // final words in place (kernels.cu:244-249): fill length = distance between consecutive run
                 // ends; an all-literal segment (dense bitmaps) is final already
                 if (any_fill) {
-                    // four batches per trip: 12 LDS reads in flight, then the arithmetic, then 4 writes
-                    for (u32 j0 = lane; j0 < count; j0 += 256) {
+                    // four batches (256 words) per trip: 12 LDS reads in flight, then the arithmetic, then 4 writes.
+                    // Whole trips run without predicates: every lane rewrites its word (unchanged if a literal).
+                    u32 t = 0;
+                    for (; t + 256u <= count; t += 256u) {
+                        u32 *const w = lds + t;
+                        const unsigned short *const pp = pos + t;
                         u32 v[4], p1[4], p0[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const u32 j = j0 + 64u * k;
-                            const bool in = j < count;
-                            v[k] = in ? lds[j] : 1u;
-                            p1[k] = in ? (u32)pos[j + 1] : 0u;
-                            p0[k] = in ? (u32)pos[j] : 0u;
+                            v[k] = w[lane_v + 64u * k];
+                            p1[k] = pp[lane_v + 64u * k + 1u];
+                            p0[k] = pp[lane_v + 64u * k];
                         }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const u32 j = j0 + 64u * k;
                             const u32 len = (p1[k] - p0[k]) & 0xFFFFu;
-                            if (j < count && v[k] - 1u >= 0x7FFFFFFEu) lds[j] = (v[k] ? kFillOne : kFillZero) | len;
+                            w[lane_v + 64u * k] = v[k] - 1u >= 0x7FFFFFFEu ? ((v[k] ? kFillOne : kFillZero) | len) : v[k];
                         }
+                    }
+                    for (u32 j = t + lane_v; j < count; j += 64u) { // last partial trip
+                        const u32 v = lds[j];
+                        const u32 len = ((u32)pos[j + 1] - (u32)pos[j]) & 0xFFFFu;
+                        if (v - 1u >= 0x7FFFFFFEu) lds[j] = (v ? kFillOne : kFillZero) | len;
                     }
                 }
             }
@@ -576,8 +597,11 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
                 last = __hip_atomic_fetch_add((lds_u32_ptr)&s_arrived[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (u32)W - 1u;
             }
             if (uniform32(last)) {
+                // lane w: words of worker w -> DPP scan -> every worker's offset inside the tile, and the total
                 const u32 mine = lane < (u32)W ? lds_ld(&s_count[q][lane]) : 0u;
-                const u32 total = uniform32(wave_sum32(mine));
+                const u32 incl = wave_scan_incl32(mine);
+                if (lane < (u32)W) lds_st(&s_prefix[q][lane], incl - mine);
+                const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
                 if (lane == 0) {
 #ifdef WAH_DIAG
                     if (a.seg_offsets) a.seg_offsets[(u64)tile * 4 + 1] = __builtin_amdgcn_s_memrealtime();
@@ -596,24 +620,26 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
             // been resolved by the scan wave while this wave classified the current tile
             const u32 pgen = gen - 1u;
             const u32 pseg = (tile - stride) * W + wave;
-            lds_wait(&s_base_flag[pgen & 1u], pgen + 1u, a.ctrl, lane);
+            if (lds_ld(&s_base_flag[pgen & 1u]) != pgen + 1u) lds_wait(&s_base_flag[pgen & 1u], pgen + 1u, a.ctrl, lane);
             WAH_STAMP(3);
             if (pseg < a.n_segments) {
-                u64 base = uniform64(lds_ld64(&s_base[pgen & 1u]));
-                for (u32 w = 0; w < wave; ++w) base += uniform32(lds_ld(&s_count[pgen & 3u][w]));
+                const u64 base = uniform64(lds_ld64(&s_base[pgen & 1u])) + uniform32(lds_ld(&s_prefix[pgen & 3u][wave]));
 #ifndef WAH_DIAG
                 if (lane == 0 && a.seg_offsets) a.seg_offsets[pseg] = base;
 #endif
-                if (base + prev_count <= a.out_capacity) {
+                if (base < a.out_capacity) {
+                    // descriptor over this segment's slice of the output (clipped to the capacity: words past it
+                    // are dropped by the hardware, and the scan wave has already raised the capacity error)
+                    const u64 room = a.out_capacity - base;
+                    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + base, (room < prev_count ? (u32)room : prev_count) * 4u);
                     const u32 *src = s_out[pgen & 1u][wave];
-                    char *dst = reinterpret_cast<char *>(a.out + base); // wave-uniform base + 32-bit lane offset
-                    for (u32 j0 = lane; j0 < prev_count; j0 += 256) { // four LDS reads in flight, then four stores
+                    const u32 off = lane_v * 4u;
+                    for (u32 t = 0; t < prev_count; t += 256u) { // four LDS reads in flight, then four dense stores
                         u32 v[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = j0 + 64u * k < prev_count ? src[j0 + 64u * k] : 0u;
+                        for (int k = 0; k < 4; ++k) v[k] = src[t + lane_v + 64u * k];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (j0 + 64u * k < prev_count) *reinterpret_cast<u32 *>(dst + (u64)((j0 + 64u * k) * 4u)) = v[k];
+                        for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(v[k], rsrc, off + 256u * k, t * 4u, 0);
                     }
                 }
             }
