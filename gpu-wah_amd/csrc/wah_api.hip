@@ -211,6 +211,8 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
     a.n_segments = (uint32_t)l.n_segments;
     a.n_tiles = (uint32_t)l.n_tiles;
     a.fast_segments = aligned16(d_in) ? 1u : 0u;
+    a.full_segments = (uint32_t)(n_words / wah::kSegWords);
+    a.tail_bytes = (uint32_t)(n_words % wah::kSegWords) * 4u;
     a.last_segment_groups = (uint32_t)(l.n_groups - (l.n_segments - 1) * wah::kSegGroups);
     a.out = d_out;
     a.out_capacity = out_capacity_words;

@@ -46,6 +46,8 @@ struct CompressArgs {
     uint32_t n_tiles;             // ceil(n_segments / kCompressWaves)
     uint32_t fast_segments;       // 1: input 16-byte aligned -> prefetched buffer loads; 0: scalar staging
     uint32_t last_segment_groups; // groups of the last segment (1..1024)
+    uint32_t full_segments;       // n_words / 992: segments that lie wholly inside the bitmap
+    uint32_t tail_bytes;          // bytes of the partial segment after them (0 if none)
     uint32_t *out;
     uint64_t out_capacity;
     uint64_t *out_words;   // device scalar: C

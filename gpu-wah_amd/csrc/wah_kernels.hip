@@ -231,9 +231,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, u32 b
 // issue the four coalesced 16-byte loads of one segment (3968 B = 248 x 16 B; lanes 56..63 of the fourth load and
 // everything past the end of the bitmap read as zero)
 __device__ __forceinline__ void prefetch_segment(const CompressArgs &a, u32 seg, u32 lane, Prefetch &p) {
-    const u64 w0 = (u64)seg * kSegWords;
-    const u64 left = a.n_words > w0 ? a.n_words - w0 : 0;
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.in + w0, left < kSegWords ? (u32)left * 4u : kSegWords * 4u);
+    // whole segments: 3968 bytes; the (one) partial segment at the end of the bitmap: what is left of it
+    const u32 bytes = seg < a.full_segments ? kSegWords * 4u : a.tail_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.in + (u64)seg * kSegWords, bytes);
     const u32 off = lane * 16u;
     p.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
     p.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 1024u, 0, 0);
@@ -901,70 +901,13 @@ __device__ __forceinline__ u32 tile_word(const u32 *s_words, const ExpandArgs &a
     return g < a.c_words ? a.comp[g] : 0u;
 }
 
-__global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const ExpandArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 s_words[kScanTileWords];
-    __shared__ u64 s_coarse[kCoarse + 1]; // groups in front of word 64 c, relative to the tile start
-    __shared__ u64 s_wave_sum[kExpandWaves];
-    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][kSegGroups]; // 1: a word starts at this group
-
-    const u32 lane = lane_id();
-    const u32 wave = wave_id();
-    const u32 tile = blockIdx.x;
-    const u64 tile_w0 = (u64)tile * kScanTileWords;
-    const u64 groups = a.info[1];
-    const u64 out_words = a.info[0];
-    if (out_words > a.out_capacity) {
-        if (threadIdx.x == 0 && tile == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
-        return;
-    }
-
-    // ---- stage the tile and build the coarse prefix of group counts --------------------------------------------
-    constexpr int kVec = kExpandWordsPerThread / 4;
-    if (a.aligned16 && tile_w0 + kScanTileWords <= a.c_words) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(a.comp + tile_w0);
-        uint4 *dst = reinterpret_cast<uint4 *>(s_words);
-        uint4 v[kVec];
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) v[k] = src[k * kExpandThreads + (int)threadIdx.x]; // coalesced 16-byte loads
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) dst[k * kExpandThreads + (int)threadIdx.x] = v[k];
-    } else {
-        for (u32 i = threadIdx.x; i < (u32)kScanTileWords; i += kExpandThreads)
-            s_words[i] = tile_w0 + i < a.c_words ? a.comp[tile_w0 + i] : 0x80000000u; // past the end: empty fill
-    }
-    __syncthreads();
-    // every thread sums the counts of its own 16 consecutive words
-    u64 mine = 0;
-    {
-        const uint4 *my = reinterpret_cast<const uint4 *>(s_words + threadIdx.x * kExpandWordsPerThread);
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) {
-            const uint4 q = my[k];
-            mine += (u64)(word_groups(q.x) + word_groups(q.y) + word_groups(q.z) + word_groups(q.w));
-        }
-    }
-    const u64 incl = wave_scan_incl(mine, lane);
-    if (lane == 63) s_wave_sum[wave] = incl;
-    __syncthreads();
-    u64 excl = incl - mine;
-    for (u32 k = 0; k < wave; ++k) excl += s_wave_sum[k];
-    constexpr u32 kThreadsPer64 = 64 / kExpandWordsPerThread;
-    if (threadIdx.x % kThreadsPer64 == 0) s_coarse[threadIdx.x / kThreadsPer64] = excl; // first thread of each 64 words
-    if (threadIdx.x == kExpandThreads - 1) s_coarse[kCoarse] = excl + mine;
-    __syncthreads();
-
-    // ---- segments owned by this tile: those whose first group lies in [base, base + total) ----------------------
-    const u64 base = a.tile_base[tile];
-    const u64 total = uniform64(s_coarse[kCoarse]);
-    const u64 n_seg = (groups + kSegGroups - 1) / kSegGroups;
-    const u64 k_begin = (base + kSegGroups - 1) / kSegGroups;
-    u64 k_end = (base + total + kSegGroups - 1) / kSegGroups;
-    if (k_end > n_seg) k_end = n_seg;
-
-    unsigned char *flag = s_flag[wave];
-    const u32 o = lane >= 31 ? lane - 31 : lane;               // repack shift of this lane's output word
-    const u64 hi_half = 0x3FFFFFFF80000000ull;                 // lanes 31..61 take the groups one lane further up
-    for (u64 seg = k_begin + wave; seg < k_end; seg += kExpandWaves) {
+// ---- one output segment, general version: any counts, 64-bit positions (foreign streams with giant fills) ---------
+__device__ __forceinline__ void expand_segment_general(const ExpandArgs &a, const u32 *s_words, const u64 *s_coarse,
+                                                       unsigned char *flag, u64 tile_w0, u64 base, u64 groups,
+                                                       u64 out_words, u64 seg, u32 lane) {
+    const u32 o = lane >= 31 ? lane - 31 : lane;
+    const u64 hi_half = 0x3FFFFFFF80000000ull;
+    do {
         const u64 target = seg * kSegGroups - base; // tile-relative position of the segment's first group
         const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
         // 64-ary search over the coarse prefix: last 64-word bucket that starts at or before the target
@@ -1018,7 +961,7 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (seen < drop + nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
             if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
-            continue;
+            break;
         }
 
         // expand: group g belongs to the r-th contributing word, r = (marks at positions <= g) - 1
@@ -1056,7 +999,158 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
                 if (lane < 62 && idx < out_words) a.out[idx] = word;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } while (false);
+}
+
+// ---- one output segment, fast version: the tile expands to fewer than 2^31 groups, so every position relative to the
+// segment start fits a signed 32-bit integer; bookkeeping stays in vector registers (see compress_kernel) ----------
+__device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, const u32 *s_words, const u32 *s_coarse32,
+                                                    unsigned char *flag, u64 tile_w0, u32 target, u32 nvalid,
+                                                    u64 out_words, u64 seg, u32 lane) {
+    // 64-ary search over the coarse prefix: last 64-word bucket that starts at or before the target
+    const u32 c = lane <= kCoarse ? s_coarse32[lane] : 0xFFFFFFFFu;
+    const u32 bucket = (u32)__popcll(__ballot(lane < kCoarse && c <= target)) - 1u;
+    int rel = (int)(uniform32(s_coarse32[bucket]) - target); // <= 0: where the bucket starts, seen from the segment
+
+    reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // flag the first group of every word that contributes to the segment (clipped at the segment start)
+    u32 first_word = 0; // tile-local index of the word that covers the segment's first group: in the first batch
+    u32 n_words_used = 0;
+    const u32 left_in_stream = a.c_words - tile_w0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(a.c_words - tile_w0);
+    for (u32 wi = bucket * 64u; rel < (int)nvalid && wi < left_in_stream; wi += 64u) {
+        const u32 idx = wi + lane;
+        const bool in = idx < left_in_stream;
+        const u32 ww = in ? tile_word(s_words, a, tile_w0, idx) : 0x80000000u; // past the end: empty fill
+        const u32 n = word_groups(ww);
+        // all literals (dense data): consecutive positions, no scan; otherwise a DPP scan
+        const u32 incl = __ballot((int)ww < 0) == 0 ? lane + 1u : wave_scan_incl32(n);
+        const int lo = rel + (int)(incl - n), hi = rel + (int)incl; // the word covers [lo, hi)
+        const bool contributes = n != 0u && hi > 0 && lo < (int)nvalid;
+        if (contributes) flag[lo > 0 ? lo : 0] = 1; // distinct groups: plain byte stores, no atomics
+        const u64 cmask = __ballot(contributes);
+        if (wi == bucket * 64u) first_word = wi + (u32)__ffsll((long long)cmask) - 1u;
+        n_words_used += (u32)__popcll(cmask);
+        rel += (int)(u32)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (rel < (int)nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
+        if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+        return;
+    }
+
+    // expand: group g belongs to the r-th contributing word, r = (flags at positions <= g) - 1
+    const bool whole = nvalid == kSegGroups && (seg + 1) * kSegWords <= out_words;   // wave-uniform
+    const bool local = first_word + n_words_used <= (u32)kScanTileWords;             // all source words inside the tile
+    const u64 seg_w0 = seg * kSegWords;
+    const u32 seg_words = whole ? kSegWords : (out_words > seg_w0 ? (u32)(out_words - seg_w0 < kSegWords ? out_words - seg_w0 : kSegWords) : 0u);
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + seg_w0, seg_words * 4u); // stores past the end are dropped
+    const u32 o = lane >= 31 ? lane - 31 : lane;     // repack shift of this lane's output word
+    const u64 hi_half = 0x3FFFFFFF80000000ull;       // lanes 31..61 take the groups one lane further up
+    const u32 soff = lane < 62 ? lane * 4u : 0xFFFFF000u; // lanes 62, 63 own no output word: out of range
+    u32 before;                                      // first_word + flags in earlier steps - 1, kept in a VGPR
+    asm volatile("v_mov_b32 %0, %1" : "=v"(before) : "s"(first_word - 1u));
+#pragma unroll
+    for (int s = 0; s < (int)kSteps; ++s) {
+        const u64 m = __ballot(flag[64 * s + (int)lane] != 0); // word starts among this step's 64 groups
+        const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, before));
+        const u32 r = below + (__builtin_amdgcn_inverse_ballot_w64(m) ? 1u : 0u);
+        before = add_popcount(before, m);
+        const u32 src_word = local ? s_words[r] : tile_word(s_words, a, tile_w0, r);
+        // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354)
+        const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
+        u32 grp = (int)src_word < 0 ? fill_val : src_word;
+        if (!whole && (u32)(64 * s) + lane >= nvalid) grp = 0u;
+        // 31 -> 32 repack (mergeWords, kernels.cu:375): output word 62 s + l takes stream bits
+        // [32 (62 s + l), +32) = groups 64 s + l + (l >= 31) and the next one, shifted by l mod 31
+        const u32 g1 = __builtin_amdgcn_update_dpp(0u, grp, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        const u32 g2 = __builtin_amdgcn_update_dpp(0u, g1, 0x130, 0xf, 0xf, false);
+        const bool up = __builtin_amdgcn_inverse_ballot_w64(hi_half);
+        const u32 a0 = up ? g1 : grp;
+        const u32 a1 = up ? g2 : g1;
+        const u32 word = (a0 >> o) | (a1 << (31u - o));
+        __builtin_amdgcn_raw_buffer_store_b32(word, rsrc, soff + 248u * s, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+__global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const ExpandArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 s_words[kScanTileWords];
+    __shared__ u64 s_coarse[kCoarse + 1]; // groups in front of word 64 c, relative to the tile start
+    __shared__ u32 s_coarse32[kCoarse + 1]; // the same in 32 bits (valid when the tile total is below 2^31)
+    __shared__ u64 s_wave_sum[kExpandWaves];
+    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][kSegGroups]; // 1: a word starts at this group
+
+    const u32 lane = lane_id();
+    const u32 wave = wave_id();
+    const u32 tile = blockIdx.x;
+    const u64 tile_w0 = (u64)tile * kScanTileWords;
+    const u64 groups = a.info[1];
+    const u64 out_words = a.info[0];
+    if (out_words > a.out_capacity) {
+        if (threadIdx.x == 0 && tile == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+        return;
+    }
+
+    // ---- stage the tile and build the coarse prefix of group counts --------------------------------------------
+    constexpr int kVec = kExpandWordsPerThread / 4;
+    if (a.aligned16 && tile_w0 + kScanTileWords <= a.c_words) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.comp + tile_w0);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_words);
+        uint4 v[kVec];
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) v[k] = src[k * kExpandThreads + (int)threadIdx.x]; // coalesced 16-byte loads
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) dst[k * kExpandThreads + (int)threadIdx.x] = v[k];
+    } else {
+        for (u32 i = threadIdx.x; i < (u32)kScanTileWords; i += kExpandThreads)
+            s_words[i] = tile_w0 + i < a.c_words ? a.comp[tile_w0 + i] : 0x80000000u; // past the end: empty fill
+    }
+    __syncthreads();
+    // every thread sums the counts of its own 16 consecutive words
+    u64 mine = 0;
+    {
+        const uint4 *my = reinterpret_cast<const uint4 *>(s_words + threadIdx.x * kExpandWordsPerThread);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) {
+            const uint4 q = my[k];
+            mine += (u64)(word_groups(q.x) + word_groups(q.y) + word_groups(q.z) + word_groups(q.w));
+        }
+    }
+    const u64 incl = wave_scan_incl(mine, lane);
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    u64 excl = incl - mine;
+    for (u32 k = 0; k < wave; ++k) excl += s_wave_sum[k];
+    constexpr u32 kThreadsPer64 = 64 / kExpandWordsPerThread;
+    if (threadIdx.x % kThreadsPer64 == 0) { // first thread of each 64 words
+        s_coarse[threadIdx.x / kThreadsPer64] = excl;
+        s_coarse32[threadIdx.x / kThreadsPer64] = (u32)excl;
+    }
+    if (threadIdx.x == kExpandThreads - 1) {
+        s_coarse[kCoarse] = excl + mine;
+        s_coarse32[kCoarse] = (u32)(excl + mine);
+    }
+    __syncthreads();
+
+    // ---- segments owned by this tile: those whose first group lies in [base, base + total) ----------------------
+    const u64 base = a.tile_base[tile];
+    const u64 total = uniform64(s_coarse[kCoarse]);
+    const u64 n_seg = (groups + kSegGroups - 1) / kSegGroups;
+    const u64 k_begin = (base + kSegGroups - 1) / kSegGroups;
+    u64 k_end = (base + total + kSegGroups - 1) / kSegGroups;
+    if (k_end > n_seg) k_end = n_seg;
+
+    unsigned char *flag = s_flag[wave];
+    const bool tame = total < (1ull << 31); // wave-uniform: positions inside this tile fit 32 bits
+    for (u64 seg = k_begin + wave; seg < k_end; seg += kExpandWaves) {
+        if (tame) {
+            const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
+            expand_segment_tame(a, s_words, s_coarse32, flag, tile_w0, (u32)(seg * kSegGroups - base), nvalid, out_words, seg, lane);
+        } else {
+            expand_segment_general(a, s_words, s_coarse, flag, tile_w0, base, groups, out_words, seg, lane);
+        }
     }
 }
 
