@@ -1002,6 +1002,40 @@ __device__ __forceinline__ void expand_segment_general(const ExpandArgs &a, cons
     } while (false);
 }
 
+// The 16 steps of one output segment: 64 groups -> 62 output words each.  kWhole: all 1024 groups exist and the
+// whole segment lies inside the output; kLocal: every source word is inside the LDS-resident tile.  (Template
+// parameters so that the step body is straight-line code.)
+template <bool kWhole, bool kLocal>
+__device__ __forceinline__ void expand_steps(const ExpandArgs &a, const u32 *s_words, const unsigned char *flag, u64 tile_w0,
+                                             __amdgpu_buffer_rsrc_t rsrc, u32 first_word, u32 nvalid, u32 lane) {
+    const u32 o = lane >= 31 ? lane - 31 : lane;          // repack shift of this lane's output word
+    const u64 hi_half = 0x3FFFFFFF80000000ull;            // lanes 31..61 take the groups one lane further up
+    const u32 soff = lane < 62 ? lane * 4u : 0xFFFFF000u; // lanes 62, 63 own no output word: out of range, dropped
+    u32 before;                                           // first_word + flags in earlier steps - 1, kept in a VGPR
+    asm volatile("v_mov_b32 %0, %1" : "=v"(before) : "s"(first_word - 1u));
+#pragma unroll
+    for (int s = 0; s < (int)kSteps; ++s) {
+        const u64 m = __ballot(flag[64 * s + (int)lane] != 0); // word starts among this step's 64 groups
+        const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, before));
+        const u32 r = below + (__builtin_amdgcn_inverse_ballot_w64(m) ? 1u : 0u);
+        before = add_popcount(before, m);
+        const u32 src_word = kLocal ? s_words[r] : tile_word(s_words, a, tile_w0, r);
+        // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354)
+        const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
+        u32 grp = (int)src_word < 0 ? fill_val : src_word;
+        if (!kWhole && (u32)(64 * s) + lane >= nvalid) grp = 0u;
+        // 31 -> 32 repack (mergeWords, kernels.cu:375): output word 62 s + l takes stream bits
+        // [32 (62 s + l), +32) = groups 64 s + l + (l >= 31) and the next one, shifted by l mod 31
+        const u32 g1 = __builtin_amdgcn_update_dpp(0u, grp, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+        const u32 g2 = __builtin_amdgcn_update_dpp(0u, g1, 0x130, 0xf, 0xf, false);
+        const bool up = __builtin_amdgcn_inverse_ballot_w64(hi_half);
+        const u32 a0 = up ? g1 : grp;
+        const u32 a1 = up ? g2 : g1;
+        const u32 word = (a0 >> o) | (a1 << (31u - o));
+        __builtin_amdgcn_raw_buffer_store_b32(word, rsrc, soff + 248u * s, 0, 0);
+    }
+}
+
 // ---- one output segment, fast version: the tile expands to fewer than 2^31 groups, so every position relative to the
 // segment start fits a signed 32-bit integer; bookkeeping stays in vector registers (see compress_kernel) ----------
 __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, const u32 *s_words, const u32 *s_coarse32,
@@ -1016,24 +1050,25 @@ __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, const u
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     // flag the first group of every word that contributes to the segment (clipped at the segment start)
-    u32 first_word = 0; // tile-local index of the word that covers the segment's first group: in the first batch
-    u32 n_words_used = 0;
     const u32 left_in_stream = a.c_words - tile_w0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(a.c_words - tile_w0);
-    for (u32 wi = bucket * 64u; rel < (int)nvalid && wi < left_in_stream; wi += 64u) {
+    // one batch = the next 64 words: flags the groups where contributing words start, returns the mask of those words
+    u32 wi = bucket * 64u;
+    auto mark_batch = [&]() -> u64 {
         const u32 idx = wi + lane;
-        const bool in = idx < left_in_stream;
-        const u32 ww = in ? tile_word(s_words, a, tile_w0, idx) : 0x80000000u; // past the end: empty fill
+        const u32 ww = idx < left_in_stream ? tile_word(s_words, a, tile_w0, idx) : 0x80000000u; // past the end: empty fill
         const u32 n = word_groups(ww);
         // all literals (dense data): consecutive positions, no scan; otherwise a DPP scan
         const u32 incl = __ballot((int)ww < 0) == 0 ? lane + 1u : wave_scan_incl32(n);
         const int lo = rel + (int)(incl - n), hi = rel + (int)incl; // the word covers [lo, hi)
         const bool contributes = n != 0u && hi > 0 && lo < (int)nvalid;
         if (contributes) flag[lo > 0 ? lo : 0] = 1; // distinct groups: plain byte stores, no atomics
-        const u64 cmask = __ballot(contributes);
-        if (wi == bucket * 64u) first_word = wi + (u32)__ffsll((long long)cmask) - 1u;
-        n_words_used += (u32)__popcll(cmask);
         rel += (int)(u32)__builtin_amdgcn_readlane((int)incl, 63);
-    }
+        wi += 64u;
+        return __ballot(contributes);
+    };
+    // the word that covers the segment's first group is in the first batch (that is how the bucket was chosen)
+    const u32 first_word = bucket * 64u + (u32)__ffsll((long long)mark_batch()) - 1u;
+    while (rel < (int)nvalid && wi < left_in_stream) (void)mark_batch();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (rel < (int)nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
         if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
@@ -1042,35 +1077,17 @@ __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, const u
 
     // expand: group g belongs to the r-th contributing word, r = (flags at positions <= g) - 1
     const bool whole = nvalid == kSegGroups && (seg + 1) * kSegWords <= out_words;   // wave-uniform
-    const bool local = first_word + n_words_used <= (u32)kScanTileWords;             // all source words inside the tile
+    const bool local = wi <= (u32)kScanTileWords; // every batch came out of the LDS-resident tile
     const u64 seg_w0 = seg * kSegWords;
     const u32 seg_words = whole ? kSegWords : (out_words > seg_w0 ? (u32)(out_words - seg_w0 < kSegWords ? out_words - seg_w0 : kSegWords) : 0u);
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + seg_w0, seg_words * 4u); // stores past the end are dropped
-    const u32 o = lane >= 31 ? lane - 31 : lane;     // repack shift of this lane's output word
-    const u64 hi_half = 0x3FFFFFFF80000000ull;       // lanes 31..61 take the groups one lane further up
-    const u32 soff = lane < 62 ? lane * 4u : 0xFFFFF000u; // lanes 62, 63 own no output word: out of range
-    u32 before;                                      // first_word + flags in earlier steps - 1, kept in a VGPR
-    asm volatile("v_mov_b32 %0, %1" : "=v"(before) : "s"(first_word - 1u));
-#pragma unroll
-    for (int s = 0; s < (int)kSteps; ++s) {
-        const u64 m = __ballot(flag[64 * s + (int)lane] != 0); // word starts among this step's 64 groups
-        const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, before));
-        const u32 r = below + (__builtin_amdgcn_inverse_ballot_w64(m) ? 1u : 0u);
-        before = add_popcount(before, m);
-        const u32 src_word = local ? s_words[r] : tile_word(s_words, a, tile_w0, r);
-        // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354)
-        const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
-        u32 grp = (int)src_word < 0 ? fill_val : src_word;
-        if (!whole && (u32)(64 * s) + lane >= nvalid) grp = 0u;
-        // 31 -> 32 repack (mergeWords, kernels.cu:375): output word 62 s + l takes stream bits
-        // [32 (62 s + l), +32) = groups 64 s + l + (l >= 31) and the next one, shifted by l mod 31
-        const u32 g1 = __builtin_amdgcn_update_dpp(0u, grp, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        const u32 g2 = __builtin_amdgcn_update_dpp(0u, g1, 0x130, 0xf, 0xf, false);
-        const bool up = __builtin_amdgcn_inverse_ballot_w64(hi_half);
-        const u32 a0 = up ? g1 : grp;
-        const u32 a1 = up ? g2 : g1;
-        const u32 word = (a0 >> o) | (a1 << (31u - o));
-        __builtin_amdgcn_raw_buffer_store_b32(word, rsrc, soff + 248u * s, 0, 0);
+    if (whole) {
+        if (local)
+            expand_steps<true, true>(a, s_words, flag, tile_w0, rsrc, first_word, nvalid, lane);
+        else
+            expand_steps<true, false>(a, s_words, flag, tile_w0, rsrc, first_word, nvalid, lane);
+    } else {
+        expand_steps<false, false>(a, s_words, flag, tile_w0, rsrc, first_word, nvalid, lane);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
