@@ -59,7 +59,7 @@ def parse():
     return ap.parse_args()
 
 
-def timed_steps(step, steps, warmup, dist=None, device=None):
+def timed_steps(step, steps, warmup, dist=None, device=None, reduce_device=None):
     """The measurement contract: W untimed steps, then exactly K steps between two barriers (+ device syncs), and
     the MAX over ranks of the wall time.  `dist` is torch.distributed (or None), `device` a CUDA device (or None on
     the CPU rehearsal)."""
@@ -82,7 +82,8 @@ def timed_steps(step, steps, warmup, dist=None, device=None):
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+        where = reduce_device if reduce_device is not None else (device if device is not None else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=where)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
@@ -127,6 +128,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # WAH_BENCH_REHEARSE=1: rehearsal of the N>1 path on a box with fewer GPUs than ranks -- ranks share the cards
+    # round robin and rendezvous over gloo (RCCL refuses two ranks on one device).  Numbers from it mean nothing.
+    rehearse = os.environ.get("WAH_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dist = None
@@ -134,7 +140,11 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    red_dev = "cpu" if rehearse else dev  # where the two small reductions live
 
     wah = importlib.import_module("gpu-wah_amd")
     wah.lib()
@@ -154,9 +164,9 @@ def main():
         step()
         comp.status()
         c_words_rank = float(sum(int(s.item()) for s in sizes))
-        elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
+        elapsed = timed_steps(step, args.steps, args.warmup, dist, dev, red_dev)
         comp.status()
-        stats = torch.tensor([4.0 * n * len(cols), c_words_rank], dtype=torch.float64, device=dev)
+        stats = torch.tensor([4.0 * n * len(cols), c_words_rank], dtype=torch.float64, device=red_dev)
         if dist is not None:
             dist.all_reduce(stats)
         if rank == 0:
@@ -199,7 +209,7 @@ def main():
         ev[2].record()
         events.append(ev)
 
-    elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
+    elapsed = timed_steps(step, args.steps, args.warmup, dist, dev, red_dev)
     comp.status()
     dec.status()
     timed = events[args.warmup:]

@@ -95,10 +95,6 @@ __device__ __forceinline__ u64 uniform64(u64 v) {
     return ((u64)uniform32((u32)(v >> 32)) << 32) | uniform32((u32)v);
 }
 
-// Number of set bits of a wave-uniform mask below this lane (v_mbcnt pair).
-__device__ __forceinline__ u32 rank_below(u64 m) {
-    return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-}
 
 // Arrival ticket: the order in which workgroups actually start running.  Tiles are dealt round robin in THIS
 // order (never in blockIdx order, which says nothing about dispatch), so a workgroup only ever waits for
@@ -354,6 +350,7 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
 //  emitted as a FLAT instruction, which counts on the vector-memory counter as well and forces vmcnt(0) waits)
 using lds_u32_ptr = __attribute__((address_space(3))) u32 *;
 using lds_u64_ptr = __attribute__((address_space(3))) u64 *;
+using lds_u8_ptr = __attribute__((address_space(3))) unsigned char *;
 __device__ __forceinline__ u32 lds_ld(const u32 *p) {
     return __hip_atomic_load((lds_u32_ptr)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -901,106 +898,11 @@ __device__ __forceinline__ u32 tile_word(const u32 *s_words, const ExpandArgs &a
     return g < a.c_words ? a.comp[g] : 0u;
 }
 
-// ---- one output segment, general version: any counts, 64-bit positions (foreign streams with giant fills) ---------
-__device__ __forceinline__ void expand_segment_general(const ExpandArgs &a, const u32 *s_words, const u64 *s_coarse,
-                                                       unsigned char *flag, u64 tile_w0, u64 base, u64 groups,
-                                                       u64 out_words, u64 seg, u32 lane) {
-    const u32 o = lane >= 31 ? lane - 31 : lane;
-    const u64 hi_half = 0x3FFFFFFF80000000ull;
-    do {
-        const u64 target = seg * kSegGroups - base; // tile-relative position of the segment's first group
-        const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
-        // 64-ary search over the coarse prefix: last 64-word bucket that starts at or before the target
-        const u64 c = lane < kCoarse ? s_coarse[lane] : ~0ull;
-        const u32 bucket = (u32)__popcll(__ballot(c <= target)) - 1u;
-        const u64 drop = target - uniform64(s_coarse[bucket]); // groups of the bucket in front of the segment
-
-        reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-        // mark the first group of every word that contributes to the segment (clipped at the segment start)
-        u32 first_word = 0; // tile-local index of the word that covers the segment's first group
-        bool have_first = false;
-        u64 seen = 0;       // groups of the words looked at so far, from the bucket start
-        u32 wi = bucket * 64u;
-        while (seen < drop + nvalid && tile_w0 + wi < a.c_words) {
-            const u32 idx = wi + lane;
-            const bool in = tile_w0 + idx < a.c_words;
-            const u32 ww = in ? tile_word(s_words, a, tile_w0, idx) : 0u;
-            const u32 n = in ? word_groups(ww) : 0u;
-            bool contributes;
-            u32 p = 0;
-            u64 batch_total;
-            if (__ballot(n > (1u << 20)) == 0 && drop - (seen < drop ? seen : drop) < (1ull << 27)) {
-                // common case: everything fits 32 bits relative to `seen`.  All literals (dense data): the
-                // positions are consecutive, no scan at all; otherwise a DPP scan.
-                const u32 n_in = (u32)__popcll(__ballot(in)); // (ballots must not sit inside a per-lane select)
-                const u32 incl_n = __ballot((int)ww < 0) == 0 ? (in ? lane + 1u : n_in) : wave_scan_incl32(n);
-                const u32 lead = (u32)(drop - (seen < drop ? seen : drop)); // groups still to drop in this batch
-                const u32 past = seen > drop ? (u32)(seen - drop) : 0u;     // segment groups already covered
-                const u32 lo = incl_n - n, hi = incl_n;
-                contributes = n != 0 && hi > lead && lo + past < lead + nvalid;
-                p = (lo > lead ? lo - lead : 0u) + past;
-                batch_total = (u32)__builtin_amdgcn_readlane((int)incl_n, 63);
-            } else {
-                const u64 incl_n = wave_scan_incl((u64)n, lane);
-                const u64 lo = seen + (incl_n - n), hi = seen + incl_n; // the word covers [lo, hi) from the bucket start
-                contributes = n != 0 && hi > drop && lo < drop + nvalid;
-                p = lo > drop ? (u32)(lo - drop) : 0u;
-                batch_total = uniform64(__shfl(incl_n, 63));
-            }
-            if (contributes) flag[p] = 1; // distinct groups: plain byte stores, no atomics
-            const u64 cmask = __ballot(contributes);
-            if (!have_first && cmask) {
-                first_word = uniform32(wi + (u32)__ffsll((long long)cmask) - 1u);
-                have_first = true;
-            }
-            seen += batch_total;
-            wi += 64u;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (seen < drop + nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
-            if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
-            break;
-        }
-
-        // expand: group g belongs to the r-th contributing word, r = (marks at positions <= g) - 1
-        const bool whole = nvalid == kSegGroups && (seg + 1) * kSegWords <= out_words; // wave-uniform
-        u32 *const dst = a.out + seg * kSegWords; // wave-uniform base: stores use base + lane*4 + 248*s
-        u32 before = 0;                           // marks in earlier steps
-#pragma unroll
-        for (int s = 0; s < (int)kSteps; ++s) {
-            const u64 m = __ballot(flag[64 * s + (int)lane] != 0); // word starts among this step's 64 groups
-            // inclusive rank - 1 = marks below me + (mark at me) - 1
-            const u32 r = rank_below(m) + (__builtin_amdgcn_inverse_ballot_w64(m) ? 1u : 0u) + (first_word + before - 1u);
-            before += (u32)__popcll(m);
-            u32 src_word;
-            if (first_word + before <= (u32)kScanTileWords) // every word of this step is inside the tile (uniform)
-                src_word = s_words[r];
-            else
-                src_word = tile_word(s_words, a, tile_w0, r);
-            // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354)
-            const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
-            u32 grp = (int)src_word < 0 ? fill_val : src_word;
-            if (!whole && (u32)(64 * s) + lane >= nvalid) grp = 0u;
-
-            // 31 -> 32 repack (mergeWords, kernels.cu:375): output word 62 s + l takes stream bits
-            // [32 (62 s + l), +32) = groups 64 s + l + (l >= 31) and the next one, shifted by l mod 31
-            const u32 g1 = __builtin_amdgcn_update_dpp(0u, grp, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-            const u32 g2 = __builtin_amdgcn_update_dpp(0u, g1, 0x130, 0xf, 0xf, false);
-            const bool up = __builtin_amdgcn_inverse_ballot_w64(hi_half);
-            const u32 a0 = up ? g1 : grp;
-            const u32 a1 = up ? g2 : g1;
-            const u32 word = (a0 >> o) | (a1 << (31u - o));
-            if (whole) {
-                if (lane < 62) dst[62 * s + (int)lane] = word;
-            } else {
-                const u64 idx = seg * kSegWords + 62u * s + lane;
-                if (lane < 62 && idx < out_words) a.out[idx] = word;
-            }
-        }
-    } while (false);
-}
+// Flags of one output segment: the byte for group p lives at (p % 64) * 16 + p / 64, so that ONE 16-byte LDS read
+// hands a lane the flags of its group in all 16 steps.  Behind the 1024 flags a dump area takes the stores of lanes
+// that have nothing to flag (cheaper than masking them off).
+constexpr u32 kFlagBytes = kSegGroups + 64;
+__device__ __forceinline__ u32 flag_slot(u32 p) { return ((p & 63u) << 4) | (p >> 6); }
 
 // The 16 steps of one output segment: 64 groups -> 62 output words each.  kWhole: all 1024 groups exist and the
 // whole segment lies inside the output; kLocal: every source word is inside the LDS-resident tile.  (Template
@@ -1008,76 +910,39 @@ __device__ __forceinline__ void expand_segment_general(const ExpandArgs &a, cons
 template <bool kWhole, bool kLocal>
 __device__ __forceinline__ void expand_steps(const ExpandArgs &a, const u32 *s_words, const unsigned char *flag, u64 tile_w0,
                                              __amdgpu_buffer_rsrc_t rsrc, u32 first_word, u32 nvalid, u32 lane) {
-    const u32 o = lane >= 31 ? lane - 31 : lane;          // repack shift of this lane's output word
-    const u64 hi_half = 0x3FFFFFFF80000000ull;            // lanes 31..61 take the groups one lane further up
-    const u32 soff = lane < 62 ? lane * 4u : 0xFFFFF000u; // lanes 62, 63 own no output word: out of range, dropped
-    u32 before;                                           // first_word + flags in earlier steps - 1, kept in a VGPR
-    asm volatile("v_mov_b32 %0, %1" : "=v"(before) : "s"(first_word - 1u));
+    // 31 -> 32 repack (mergeWords, kernels.cu:375): output word 62 s + l takes stream bits [32 (62 s + l), +32) =
+    // groups 64 s + l + (l >= 31) and the next one, shifted by l mod 31.  Lane L decodes group 64 s + L; lanes 0..30
+    // build words 0..30 and lanes 32..62 words 31..61 from their own group and the neighbour's (one DPP shift),
+    // lanes 31 and 63 only lend their group.
+    const u32 o = lane & 31u;
+    const u32 up = 31u - ((lane - 1u) & 31u);             // what my group is shifted up by in my LEFT neighbour's word
+    const u32 soff = o != 31u ? (lane - (lane >> 5)) * 4u : 0xFFFFF000u; // lanes 31, 63: out of range, dropped
+    const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
+    const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
+    u32 before4 = (first_word - 1u) * 4u;                 // byte offset of (first_word + flags in earlier steps - 1)
 #pragma unroll
     for (int s = 0; s < (int)kSteps; ++s) {
-        const u64 m = __ballot(flag[64 * s + (int)lane] != 0); // word starts among this step's 64 groups
-        const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, before));
-        const u32 r = below + (__builtin_amdgcn_inverse_ballot_w64(m) ? 1u : 0u);
-        before = add_popcount(before, m);
-        const u32 src_word = kLocal ? s_words[r] : tile_word(s_words, a, tile_w0, r);
+        const u32 fb = (f[s >> 2] >> (8 * (s & 3))) & 0xFFu;  // 1: a word starts at my group
+        const u64 m = __ballot(fb != 0u);
+        // inclusive rank among this step's flags (the count is seeded with my own flag), plus all earlier ones
+        const u32 r4 = (__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, fb)) << 2) + before4;
+        before4 = (u32)__builtin_amdgcn_readlane((int)r4, 63); // the last lane's rank counts every flag so far
+        const u32 src_word = kLocal ? *reinterpret_cast<const u32 *>(reinterpret_cast<const unsigned char *>(s_words) + r4)
+                                    : tile_word(s_words, a, tile_w0, r4 >> 2);
         // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354)
         const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
         u32 grp = (int)src_word < 0 ? fill_val : src_word;
         if (!kWhole && (u32)(64 * s) + lane >= nvalid) grp = 0u;
-        // 31 -> 32 repack (mergeWords, kernels.cu:375): output word 62 s + l takes stream bits
-        // [32 (62 s + l), +32) = groups 64 s + l + (l >= 31) and the next one, shifted by l mod 31
-        const u32 g1 = __builtin_amdgcn_update_dpp(0u, grp, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        const u32 g2 = __builtin_amdgcn_update_dpp(0u, g1, 0x130, 0xf, 0xf, false);
-        const bool up = __builtin_amdgcn_inverse_ballot_w64(hi_half);
-        const u32 a0 = up ? g1 : grp;
-        const u32 a1 = up ? g2 : g1;
-        const u32 word = (a0 >> o) | (a1 << (31u - o));
+        const u32 hi_part = (u32)__builtin_amdgcn_mov_dpp((int)(grp << up), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+        const u32 word = (grp >> o) | hi_part;
         __builtin_amdgcn_raw_buffer_store_b32(word, rsrc, soff + 248u * s, 0, 0);
     }
 }
 
-// ---- one output segment, fast version: the tile expands to fewer than 2^31 groups, so every position relative to the
-// segment start fits a signed 32-bit integer; bookkeeping stays in vector registers (see compress_kernel) ----------
-__device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, const u32 *s_words, const u32 *s_coarse32,
-                                                    unsigned char *flag, u64 tile_w0, u32 target, u32 nvalid,
-                                                    u64 out_words, u64 seg, u32 lane) {
-    // 64-ary search over the coarse prefix: last 64-word bucket that starts at or before the target
-    const u32 c = lane <= kCoarse ? s_coarse32[lane] : 0xFFFFFFFFu;
-    const u32 bucket = (u32)__popcll(__ballot(lane < kCoarse && c <= target)) - 1u;
-    int rel = (int)(uniform32(s_coarse32[bucket]) - target); // <= 0: where the bucket starts, seen from the segment
-
-    reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-    // flag the first group of every word that contributes to the segment (clipped at the segment start)
-    const u32 left_in_stream = a.c_words - tile_w0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(a.c_words - tile_w0);
-    // one batch = the next 64 words: flags the groups where contributing words start, returns the mask of those words
-    u32 wi = bucket * 64u;
-    auto mark_batch = [&]() -> u64 {
-        const u32 idx = wi + lane;
-        const u32 ww = idx < left_in_stream ? tile_word(s_words, a, tile_w0, idx) : 0x80000000u; // past the end: empty fill
-        const u32 n = word_groups(ww);
-        // all literals (dense data): consecutive positions, no scan; otherwise a DPP scan
-        const u32 incl = __ballot((int)ww < 0) == 0 ? lane + 1u : wave_scan_incl32(n);
-        const int lo = rel + (int)(incl - n), hi = rel + (int)incl; // the word covers [lo, hi)
-        const bool contributes = n != 0u && hi > 0 && lo < (int)nvalid;
-        if (contributes) flag[lo > 0 ? lo : 0] = 1; // distinct groups: plain byte stores, no atomics
-        rel += (int)(u32)__builtin_amdgcn_readlane((int)incl, 63);
-        wi += 64u;
-        return __ballot(contributes);
-    };
-    // the word that covers the segment's first group is in the first batch (that is how the bucket was chosen)
-    const u32 first_word = bucket * 64u + (u32)__ffsll((long long)mark_batch()) - 1u;
-    while (rel < (int)nvalid && wi < left_in_stream) (void)mark_batch();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (rel < (int)nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
-        if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
-        return;
-    }
-
-    // expand: group g belongs to the r-th contributing word, r = (flags at positions <= g) - 1
+// flags are in place: expand the segment
+__device__ __forceinline__ void expand_emit(const ExpandArgs &a, const u32 *s_words, const unsigned char *flag, u64 tile_w0,
+                                            u32 first_word, u32 nvalid, u64 out_words, u64 seg, bool local, u32 lane) {
     const bool whole = nvalid == kSegGroups && (seg + 1) * kSegWords <= out_words;   // wave-uniform
-    const bool local = wi <= (u32)kScanTileWords; // every batch came out of the LDS-resident tile
     const u64 seg_w0 = seg * kSegWords;
     const u32 seg_words = whole ? kSegWords : (out_words > seg_w0 ? (u32)(out_words - seg_w0 < kSegWords ? out_words - seg_w0 : kSegWords) : 0u);
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + seg_w0, seg_words * 4u); // stores past the end are dropped
@@ -1092,12 +957,147 @@ __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, const u
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// ---- one output segment, general version: any counts, 64-bit positions (foreign streams with giant fills) ---------
+__device__ __forceinline__ void expand_segment_general(const ExpandArgs &a, const u32 *s_words, const u64 *s_coarse,
+                                                       unsigned char *flag, u64 tile_w0, u64 base, u64 groups,
+                                                       u64 out_words, u64 seg, u32 lane) {
+    const u64 target = seg * kSegGroups - base; // tile-relative position of the segment's first group
+    const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
+    // 64-ary search over the coarse prefix: last 64-word bucket that starts at or before the target
+    const u64 c = lane < kCoarse ? s_coarse[lane] : ~0ull;
+    const u32 bucket = (u32)__popcll(__ballot(c <= target)) - 1u;
+    const u64 drop = target - uniform64(s_coarse[bucket]); // groups of the bucket in front of the segment
+
+    reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // mark the first group of every word that contributes to the segment (clipped at the segment start)
+    u32 first_word = 0; // tile-local index of the word that covers the segment's first group
+    bool have_first = false;
+    u64 seen = 0;       // groups of the words looked at so far, from the bucket start
+    u32 wi = bucket * 64u;
+    while (seen < drop + nvalid && tile_w0 + wi < a.c_words) {
+        const u32 idx = wi + lane;
+        const bool in = tile_w0 + idx < a.c_words;
+        const u32 ww = in ? tile_word(s_words, a, tile_w0, idx) : 0u;
+        const u32 n = in ? word_groups(ww) : 0u;
+        bool contributes;
+        u32 p = 0;
+        u64 batch_total;
+        if (__ballot(n > (1u << 20)) == 0 && drop - (seen < drop ? seen : drop) < (1ull << 27)) {
+            // common case: everything fits 32 bits relative to `seen`
+            const u32 incl_n = wave_scan_incl32(n);
+            const u32 lead = (u32)(drop - (seen < drop ? seen : drop)); // groups still to drop in this batch
+            const u32 past = seen > drop ? (u32)(seen - drop) : 0u;     // segment groups already covered
+            const u32 lo = incl_n - n, hi = incl_n;
+            contributes = n != 0 && hi > lead && lo + past < lead + nvalid;
+            p = (lo > lead ? lo - lead : 0u) + past;
+            batch_total = (u32)__builtin_amdgcn_readlane((int)incl_n, 63);
+        } else {
+            const u64 incl_n = wave_scan_incl((u64)n, lane);
+            const u64 lo = seen + (incl_n - n), hi = seen + incl_n; // the word covers [lo, hi) from the bucket start
+            contributes = n != 0 && hi > drop && lo < drop + nvalid;
+            p = lo > drop ? (u32)(lo - drop) : 0u;
+            batch_total = uniform64(__shfl(incl_n, 63));
+        }
+        if (contributes) flag[flag_slot(p)] = 1; // distinct groups: plain byte stores, no atomics
+        const u64 cmask = __ballot(contributes);
+        if (!have_first && cmask) {
+            first_word = uniform32(wi + (u32)__ffsll((long long)cmask) - 1u);
+            have_first = true;
+        }
+        seen += batch_total;
+        wi += 64u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (seen < drop + nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
+        if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+        return;
+    }
+    expand_emit(a, s_words, flag, tile_w0, first_word, nvalid, out_words, seg, false, lane);
+}
+
+// ---- one output segment, fast version: the tile expands to fewer than 2^31 groups, so every position relative to the
+// segment start fits a signed 32-bit integer; bookkeeping stays in vector registers (see compress_kernel) ----------
+
+// One batch of the mark phase: the next 128 words, two per lane.  `rel` = where the batch starts, seen from the
+// segment start (<= 0 at first).  Flags the group at which every contributing word starts (clipped at the segment
+// start).  kFirst: returns the tile-local index of the first contributing word.
+template <bool kLocal, bool kFirst>
+__device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, const u32 *s_words, unsigned char *flag, u64 tile_w0,
+                                          u32 left_in_stream, u32 nvalid, u32 lane, int &rel, u32 &wi) {
+    const u32 i0 = wi + 2u * lane;
+    u32 w0, w1;
+    if (kLocal) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(s_words + i0);
+        w0 = q.x;
+        w1 = q.y;
+    } else { // past the tile: global memory; past the stream: empty fills
+        w0 = i0 < left_in_stream ? a.comp[tile_w0 + i0] : 0x80000000u;
+        w1 = i0 + 1u < left_in_stream ? a.comp[tile_w0 + i0 + 1u] : 0x80000000u;
+    }
+    const u32 n0 = word_groups(w0), n1 = word_groups(w1);
+    // all literals (dense data): consecutive positions, no scan; otherwise one DPP scan over the pair sums
+    const u32 incl = __ballot((int)(w0 | w1) < 0) == 0 ? 2u * lane + 2u : wave_scan_incl32(n0 + n1);
+    const int hi1 = rel + (int)incl, lo1 = hi1 - (int)n1, lo0 = lo1 - (int)n0; // words cover [lo0, lo1) and [lo1, hi1)
+    // clip to the segment [0, nvalid): a word contributes iff something is left of it
+    const int s0 = lo0 > 0 ? lo0 : 0, e0 = lo1 < (int)nvalid ? lo1 : (int)nvalid;
+    const int s1 = lo1 > 0 ? lo1 : 0, e1 = hi1 < (int)nvalid ? hi1 : (int)nvalid;
+    const bool c0 = e0 > s0, c1 = e1 > s1;
+    // distinct groups: plain byte stores, no atomics.  slot(p) + base = base + 16 p - 1023 (p / 64): three instructions
+    const u32 fbase = (u32)(uintptr_t)(lds_u8_ptr)flag;
+    const u32 dump = fbase + kSegGroups + lane;
+    const u32 a0 = (u32)__mul24(s0 >> 6, -1023) + (((u32)s0 << 4) + fbase);
+    const u32 a1 = (u32)__mul24(s1 >> 6, -1023) + (((u32)s1 << 4) + fbase);
+    *(lds_u8_ptr)(uintptr_t)(c0 ? a0 : dump) = 1;
+    *(lds_u8_ptr)(uintptr_t)(c1 ? a1 : dump) = 1;
+    u32 first = 0;
+    if (kFirst) {
+        const u64 m0 = __ballot(c0), m1 = __ballot(c1);
+        const u32 l = (u32)__ffsll((long long)(m0 | m1)) - 1u;
+        first = wi + 2u * l + (((m0 >> l) & 1ull) ? 0u : 1u);
+    }
+    rel += (int)(u32)__builtin_amdgcn_readlane((int)incl, 63);
+    wi += 128u;
+    return first;
+}
+
+__device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, const u32 *s_words, const u32 *s_coarse32,
+                                                    unsigned char *flag, u64 tile_w0, u32 target, u32 nvalid,
+                                                    u64 out_words, u64 seg, u32 lane) {
+    // 64-ary search over the coarse prefix: last 64-word bucket that starts at or before the target
+    const u32 c = lane <= kCoarse ? s_coarse32[lane] : 0xFFFFFFFFu;
+    const u32 bucket = (u32)__popcll(__ballot(lane < kCoarse && c <= target)) - 1u;
+    int rel = (int)(uniform32(s_coarse32[bucket]) - target); // <= 0: where the bucket starts, seen from the segment
+
+    reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    const u32 left_in_stream = a.c_words - tile_w0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(a.c_words - tile_w0);
+    u32 wi = bucket * 64u;
+    constexpr u32 kLastLocal = (u32)kScanTileWords - 128u; // batches starting up to here come out of the LDS tile
+    // the word that covers the segment's first group is in the first batch (that is how the bucket was chosen)
+    const u32 first_word = wi <= kLastLocal ? mark_pairs<true, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi)
+                                            : mark_pairs<false, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi);
+    while (rel < (int)nvalid && wi <= kLastLocal)
+        (void)mark_pairs<true, false>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi);
+    while (rel < (int)nvalid && wi < left_in_stream)
+        (void)mark_pairs<false, false>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (rel < (int)nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
+        if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+        return;
+    }
+    // group g belongs to the r-th contributing word, r = (flags at positions <= g) - 1
+    expand_emit(a, s_words, flag, tile_w0, first_word, nvalid, out_words, seg, wi <= (u32)kScanTileWords, lane);
+}
+
 __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const ExpandArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_words[kScanTileWords];
     __shared__ u64 s_coarse[kCoarse + 1]; // groups in front of word 64 c, relative to the tile start
     __shared__ u32 s_coarse32[kCoarse + 1]; // the same in 32 bits (valid when the tile total is below 2^31)
     __shared__ u64 s_wave_sum[kExpandWaves];
-    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][kSegGroups]; // 1: a word starts at this group
+    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][kFlagBytes]; // 1: a word starts at this group
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
