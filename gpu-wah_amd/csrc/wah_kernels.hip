@@ -213,6 +213,11 @@ constexpr u32 kPosEntries = 1032; // pos[0] = -1 sentinel, pos[k+1] = group posi
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
+using lds_u32_ptr = __attribute__((address_space(3))) u32 *;
+using lds_u64_ptr = __attribute__((address_space(3))) u64 *;
+using lds_u16_ptr = __attribute__((address_space(3))) unsigned short *;
+using lds_u8_ptr = __attribute__((address_space(3))) unsigned char *;
+
 struct Prefetch {
     u32x4 v[4];
 };
@@ -279,6 +284,31 @@ __device__ __forceinline__ u32 add_popcount(u32 acc, u64 mask) {
     return acc;
 }
 
+// one step of classify_compact<true> (see there); X0 / X1: operand names of this step's and the next step's groups
+#ifdef WAH_NO_BITOP3
+#define WAH_Z_INSTR(X0) "v_xor_b32 %[nx], %[" X0 "], %[nx]\n\tv_or_b32 %[nx], %[nx], %[tt]\n\t"
+#else
+#define WAH_Z_INSTR(X0) "v_bitop3_b32 %[nx], %[" X0 "], %[nx], %[tt] bitop3:0xbe\n\t"
+#endif
+#define WAH_CLASSIFY_STEP(X0, X1, K)                                          \
+    "v_mov_b32_dpp %[nx], %[" X1 "] wave_rol:1 row_mask:0xf bank_mask:0xf\n\t" \
+    "v_add_u32 %[tt], 1, %[" X0 "]\n\t"                                        \
+    "v_and_b32 %[tt], 0x7ffffffe, %[tt]\n\t"                                   \
+    "v_mov_b32_dpp %[nx], %[" X0 "] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
+    WAH_Z_INSTR(X0)                                                            \
+    "v_cmp_ne_u32 vcc, 0, %[nx]\n\t"                                           \
+    "v_min_u32 %[mt], %[mt], %[tt]\n\t"                                        \
+    "v_add_u32 %[ps], " K ", %[ln]\n\t"                                        \
+    "v_mbcnt_lo_u32_b32 %[nx], vcc_lo, %[cn]\n\t"                              \
+    "v_mbcnt_hi_u32_b32 %[nx], vcc_hi, %[nx]\n\t"                              \
+    "v_bcnt_u32_b32 %[cn], vcc_lo, %[cn]\n\t"                                  \
+    "v_bcnt_u32_b32 %[cn], vcc_hi, %[cn]\n\t"                                  \
+    "v_cndmask_b32 %[nx], %[dm], %[nx], vcc\n\t"                               \
+    "v_lshl_add_u32 %[tt], %[nx], 2, %[vb]\n\t"                                \
+    "v_lshl_add_u32 %[nx], %[nx], 1, %[pb]\n\t"                                \
+    "ds_write_b32 %[tt], %[" X0 "]\n\t"                                        \
+    "ds_write_b16 %[nx], %[ps]\n\t"
+
 template <bool kFull>
 __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigned short *pos, u32 r, u32 lane_v,
                                                 u32 nvalid, bool &any_fill) {
@@ -306,30 +336,42 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
     u32 count_v = 0;
     asm volatile("v_mov_b32 %0, 0" : "=v"(count_v)); // a VECTOR zero: keeps the running count off the scalar unit
     u32 min_t = 0xFFFFFFFFu;
-    u32 *const val_dump = lds + kStageWords; // one spare dword behind the buffer
-    unsigned short *const pos_dump = pos + (kPosEntries - 2);
+    // LDS byte addresses: value k at vbase + 4 k, its position at pbase + 2 k; k = kStageWords is the dump slot
+    const u32 vbase = (u32)(uintptr_t)(lds_u32_ptr)lds;
+    const u32 pbase = (u32)(uintptr_t)(lds_u16_ptr)pos + 2u;
+    u32 dump_slot;
+    asm volatile("v_mov_b32 %0, 0x400" : "=v"(dump_slot)); // kStageWords, in a vector register (v_cndmask cannot take a literal)
+    static_assert(kStageWords == 0x400, "dump slot literal");
+    if (kFull) {
+        // Hand-scheduled, one block for the 16 steps: 15 vector + 2 LDS instructions each, ordered so that no hazard
+        // needs a wait state (a DPP source or a v_cmp mask read as data must be two instructions old; the compiler
+        // pads with s_nop, also around every asm statement, and on this machine a nop costs an issue slot like any
+        // other instruction).
+        u32 nx, tt, ps;
+        asm volatile(WAH_CLASSIFY_STEP("x0", "x1", "0") WAH_CLASSIFY_STEP("x1", "x2", "64") WAH_CLASSIFY_STEP("x2", "x3", "128") WAH_CLASSIFY_STEP("x3", "x4", "192") WAH_CLASSIFY_STEP("x4", "x5", "256") WAH_CLASSIFY_STEP("x5", "x6", "320") WAH_CLASSIFY_STEP("x6", "x7", "384") WAH_CLASSIFY_STEP("x7", "x8", "448") WAH_CLASSIFY_STEP("x8", "x9", "512") WAH_CLASSIFY_STEP("x9", "x10", "576") WAH_CLASSIFY_STEP("x10", "x11", "640") WAH_CLASSIFY_STEP("x11", "x12", "704") WAH_CLASSIFY_STEP("x12", "x13", "768") WAH_CLASSIFY_STEP("x13", "x14", "832") WAH_CLASSIFY_STEP("x14", "x15", "896") WAH_CLASSIFY_STEP("x15", "x16", "960")
+                     : [nx] "=&v"(nx), [tt] "=&v"(tt), [ps] "=&v"(ps), [cn] "+&v"(count_v), [mt] "+&v"(min_t)
+                     : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]), [x12] "v"(x[12]), [x13] "v"(x[13]), [x14] "v"(x[14]), [x15] "v"(x[15]), [x16] "v"(x[16]),
+                       [ln] "v"(lane_v), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)
+                     : "vcc", "memory");
+        any_fill = __ballot(min_t == 0u) != 0;
+        return uniform32(count_v);
+    }
 #pragma unroll
     for (int s = 0; s < (int)kSteps; ++s) {
-        const u32 carry = __builtin_amdgcn_update_dpp(0u, x[s + 1], 0x134 /* wave_rol:1 */, 0xf, 0xf, false);
+        const u32 carry = (u32)__builtin_amdgcn_mov_dpp((int)x[s + 1], 0x134 /* wave_rol:1 */, 0xf, 0xf, true);
         const u32 nxt = __builtin_amdgcn_update_dpp(carry, x[s], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
         const u32 t = (x[s] + 1u) & 0x7FFFFFFEu; // zero <=> x is all zeros or all ones
-        const u32 z = (x[s] ^ nxt) | t;
+        const u32 z = __builtin_amdgcn_bitop3_b32(x[s], nxt, t, 0xbe); // (x ^ next) | t
         u64 e = __ballot(z != 0u);
-        if (!kFull) {
-            const int rem = (int)nvalid - 64 * s;
-            const u64 valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-            const u64 last = (rem >= 1 && rem <= 64) ? (1ull << (rem - 1)) : 0ull; // the last existing group closes its run
-            e = (e | last) & valid;
-            if (rem > 0) min_t = min(min_t, (lane_v < (u32)rem) ? t : 0xFFFFFFFFu);
-        } else {
-            min_t = min(min_t, t);
-        }
-        const bool is_end = __builtin_amdgcn_inverse_ballot_w64(e);
+        const int rem = (int)nvalid - 64 * s;
+        const u64 valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+        const u64 last = (rem >= 1 && rem <= 64) ? (1ull << (rem - 1)) : 0ull; // the last existing group closes its run
+        e = (e | last) & valid;
+        if (rem > 0) min_t = min(min_t, (lane_v < (u32)rem) ? t : 0xFFFFFFFFu);
         const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(e >> 32), __builtin_amdgcn_mbcnt_lo((u32)e, count_v));
-        u32 *const vdst = is_end ? lds + rank : val_dump;
-        unsigned short *const pdst = is_end ? pos + rank + 1 : pos_dump;
-        *vdst = x[s];
-        *pdst = (unsigned short)(64 * s + (int)lane_v);
+        const u32 slot = __builtin_amdgcn_inverse_ballot_w64(e) ? rank : kStageWords;
+        *(lds_u32_ptr)(uintptr_t)(vbase + (slot << 2)) = x[s];
+        *(lds_u16_ptr)(uintptr_t)(pbase + (slot << 1)) = (unsigned short)(64 * s + (int)lane_v);
         count_v = add_popcount(count_v, e);
     }
     any_fill = __ballot(min_t == 0u) != 0; // some group is a fill, so some emitted word is one
@@ -348,9 +390,6 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
 // never the vector-memory counter -- the prefetched loads stay in flight.
 // (explicit LDS address space + relaxed workgroup atomics: a volatile access through a generic pointer would be
 //  emitted as a FLAT instruction, which counts on the vector-memory counter as well and forces vmcnt(0) waits)
-using lds_u32_ptr = __attribute__((address_space(3))) u32 *;
-using lds_u64_ptr = __attribute__((address_space(3))) u64 *;
-using lds_u8_ptr = __attribute__((address_space(3))) unsigned char *;
 __device__ __forceinline__ u32 lds_ld(const u32 *p) {
     return __hip_atomic_load((lds_u32_ptr)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
