@@ -440,27 +440,30 @@ __device__ __forceinline__ bool lds_wait_reached(const u32 *counter, u32 value, 
     return true;
 }
 
+constexpr u32 kDepth = 8;      // generations a workgroup keeps bookkeeping for (power of two)
+constexpr u32 kMaxPending = 4; // finished tiles a worker may hold in LDS while their offsets resolve (< kDepth - 2)
+
 template <int W>
 __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_out[2][W][kOutWords];
     __shared__ unsigned short s_pos[W][kPosEntries];
-    __shared__ u32 s_count[4][W];    // words per worker of tile (gen & 3)
-    __shared__ u32 s_prefix[4][W];   // ... and the words of the workers before it
-    __shared__ u32 s_arrived[4];     // workers that have delivered their count for tile (gen & 3)
-    __shared__ u32 s_total[4];       // words of tile (gen & 3) ...
-    __shared__ u32 s_total_flag[4];  // ... valid when == gen + 1
-    __shared__ u64 s_base[2];        // output offset of tile (gen & 1) ...
-    __shared__ u32 s_base_flag[2];   // ... valid when == gen + 1
+    __shared__ u32 s_count[kDepth][W];    // words per worker of tile (gen % kDepth)
+    __shared__ u32 s_prefix[kDepth][W];   // ... and the words of the workers before it
+    __shared__ u32 s_arrived[kDepth];     // workers that have delivered their count for tile (gen % kDepth)
+    __shared__ u32 s_total[kDepth];       // words of tile (gen % kDepth) ...
+    __shared__ u32 s_total_flag[kDepth];  // ... valid when == gen + 1
+    __shared__ u64 s_base[kDepth];        // output offset of tile (gen % kDepth) ...
+    __shared__ u32 s_base_flag[kDepth];   // ... valid when == gen + 1
     __shared__ u32 s_arrival;
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
     const bool worker = wave < (u32)W;
 
-    if (threadIdx.x < 4) {
+    if (threadIdx.x < kDepth) {
         s_arrived[threadIdx.x] = 0;
         s_total_flag[threadIdx.x] = 0;
-        if (threadIdx.x < 2) s_base_flag[threadIdx.x] = 0;
+        s_base_flag[threadIdx.x] = 0;
     }
     if (threadIdx.x == 0) s_arrival = draw_arrival(a.ctrl);
     __syncthreads();
@@ -494,8 +497,9 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
         GenScan scan = {0, 0, 0};
         u32 gen = 0;
         for (u32 tile = arrival; tile < a.n_tiles; tile += stride, ++gen) {
-            if (!lds_wait(&s_total_flag[gen & 3u], gen + 1u, a.ctrl, lane)) break;
-            const u32 aggregate = uniform32(lds_ld(&s_total[gen & 3u]));
+            const u32 q = gen & (kDepth - 1u);
+            if (!lds_wait(&s_total_flag[q], gen + 1u, a.ctrl, lane)) break;
+            const u32 aggregate = uniform32(lds_ld(&s_total[q]));
             WAH_STAMP(0);
             const u64 excl = resolve_generation(a.gen_desc, gen, arrival, stride, row_stride, aggregate, scan, lane, a.ctrl);
             WAH_STAMP(1);
@@ -506,8 +510,8 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
             }
 #endif
             if (lane == 0) {
-                __hip_atomic_store((lds_u64_ptr)&s_base[gen & 1u], excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                lds_publish(&s_base_flag[gen & 1u], gen + 1u);
+                __hip_atomic_store((lds_u64_ptr)&s_base[q], excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_publish(&s_base_flag[q], gen + 1u);
                 if (tile == a.n_tiles - 1) {
                     *a.out_words = excl + aggregate;
 #ifndef WAH_DIAG
@@ -529,6 +533,13 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
     }
 
     // ---------------- worker waves -------------------------------------------------------------------------
+    // Each worker owns two 4 KiB LDS buffers.  One is the STAGE: the segment is staged, classified and compacted
+    // there.  The other is a RING of finished output words that wait for their global offset: up to kMaxPending
+    // tiles (as many as fit 1024 words), oldest first.  So the offset of a tile is not needed one iteration after
+    // it was published (the resolve latency across the chip is about one iteration of work, measured) but only
+    // when the ring runs out of room -- two or three iterations later for compressible data.  A segment that does
+    // not fit beside what is pending (incompressible data) waits for the ring to drain and then the two buffers
+    // simply swap roles, without copying.
     // regroup constants: group g = 64*step + lane starts at stream bit 31*g; 64 groups = 1984 bits = 62 words
     // exactly, so the in-word shift is fixed per lane and the word index advances by 62 per step
     const u32 r = (31u * lane) & 31u;
@@ -546,13 +557,64 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
         }
     }
 
-    u32 prev_count = 0; // words of this wave's previous segment (final, in LDS, not yet written out)
+    u32 *stage = s_out[0][wave];
+    u32 *ring = s_out[1][wave];
+    u32 pend = 0;                       // tiles in the ring: generations gen - pend .. gen - 1
+    u32 ring_head = 0;                  // ring index of the oldest pending word
+    u32 used = 0;                       // pending words
+    u32 pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0; // their word counts, oldest first
+    bool ok = true;
+
+    // stream out the oldest pending tile (kernels.cu:256 + moveData, kernels.cu:273-280); `block`: wait for its offset
+    auto emit_oldest = [&](u32 gen_now, bool block, u32 lane_v) -> bool {
+        const u32 pgen = gen_now - pend;
+        const u32 q = pgen & (kDepth - 1u);
+        if (lds_ld(&s_base_flag[q]) != pgen + 1u) {
+            if (!block) return false;
+            if (!lds_wait(&s_base_flag[q], pgen + 1u, a.ctrl, lane)) {
+                ok = false;
+                return false;
+            }
+        }
+        WAH_STAMP(3);
+        const u32 pseg = (arrival + pgen * stride) * W + wave;
+        const u32 cnt = pc0;
+        if (pseg < a.n_segments) {
+            const u64 base = uniform64(lds_ld64(&s_base[q])) + uniform32(lds_ld(&s_prefix[q][wave]));
+#ifndef WAH_DIAG
+            if (lane == 0 && a.seg_offsets) a.seg_offsets[pseg] = base;
+#endif
+            if (base < a.out_capacity && cnt != 0u) {
+                // descriptor over this segment's slice of the output (clipped to the capacity: words past it
+                // are dropped by the hardware, and the scan wave has already raised the capacity error)
+                const u64 room = a.out_capacity - base;
+                const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + base, (room < cnt ? (u32)room : cnt) * 4u);
+                const u32 off = lane_v * 4u;
+                for (u32 t = 0; t < cnt; t += 256u) { // four LDS reads in flight, then four dense stores
+                    u32 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = ring[(ring_head + t + lane_v + 64u * k) & (kStageWords - 1u)];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(v[k], rsrc, off + 256u * k, t * 4u, 0);
+                }
+            }
+        }
+        ring_head = (ring_head + cnt) & (kStageWords - 1u);
+        used -= cnt;
+        pc0 = pc1;
+        pc1 = pc2;
+        pc2 = pc3;
+        pc3 = 0;
+        --pend;
+        // later iterations overwrite these words: order the reads before those writes
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        WAH_STAMP(4);
+        return true;
+    };
+
     u32 gen = 0;
-    for (u32 tile = arrival;; tile += stride, ++gen) {
-        const bool has_cur = tile < a.n_tiles;
-        const bool has_prev = gen > 0;
+    for (u32 tile = arrival; tile < a.n_tiles && ok; tile += stride, ++gen) {
         const u32 seg = tile * W + wave;
-        u32 *const lds = s_out[gen & 1u][wave];
         u32 count = 0;
         // Opaque copy of the lane id, renewed every iteration: per-step constants derived from it (group
         // positions, LDS addresses) are then recomputed next to their use instead of being hoisted out of the
@@ -560,72 +622,43 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
         u32 lane_v = lane;
         asm volatile("" : "+v"(lane_v));
 #ifdef WAH_DIAG
-        if (threadIdx.x == 0 && has_cur && a.seg_offsets) a.seg_offsets[(u64)tile * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0 && a.seg_offsets) a.seg_offsets[(u64)tile * 4 + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
+        const bool has_seg = seg < a.n_segments;
+        if (has_seg) {
+            if (pre_valid)
+                stage_prefetched(pre, stage, lane);
+            else
+                stage_slow(a, seg, stage, lane);
+        }
+        // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        WAH_STAMP(0);
 
-        if (has_cur) {
-            if (seg < a.n_segments) {
-                if (pre_valid)
-                    stage_prefetched(pre, lds, lane);
-                else
-                    stage_slow(a, seg, lds, lane);
-            }
-            // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
+        // software prefetch of the next tile's segment: in flight during everything below
+        {
+            const u32 next_tile = tile + stride;
+            const u32 nseg = next_tile * W + wave;
+            pre_valid = next_tile < a.n_tiles && nseg < a.n_segments && a.fast_segments;
+            if (pre_valid) prefetch_segment(a, nseg, lane, pre);
+        }
+
+        bool any_fill = false;
+        if (has_seg) {
+            const u32 nvalid = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
+            if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
+            const u32 *sp = stage + ((31u * lane_v) >> 5);
+            count = nvalid == kSegGroups ? classify_compact<true>(sp, stage, pos, r, lane_v, nvalid, any_fill)
+                                         : classify_compact<false>(sp, stage, pos, r, lane_v, nvalid, any_fill);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            WAH_STAMP(0);
+        }
+        WAH_STAMP(1);
 
-            // software prefetch of the next tile's segment: in flight during everything below
-            {
-                const u32 next_tile = tile + stride;
-                const u32 nseg = next_tile * W + wave;
-                pre_valid = next_tile < a.n_tiles && nseg < a.n_segments && a.fast_segments;
-                if (pre_valid) prefetch_segment(a, nseg, lane, pre);
-            }
-
-            const bool has_seg = seg < a.n_segments;
-            if (has_seg) {
-                const u32 nvalid = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
-                if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
-                const u32 *sp = lds + ((31u * lane_v) >> 5);
-                bool any_fill = false;
-                count = nvalid == kSegGroups ? classify_compact<true>(sp, lds, pos, r, lane_v, nvalid, any_fill)
-                                             : classify_compact<false>(sp, lds, pos, r, lane_v, nvalid, any_fill);
-                WAH_STAMP(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                // final words in place (kernels.cu:244-249): fill length = distance between consecutive run
-                // ends; an all-literal segment (dense bitmaps) is final already
-                if (any_fill) {
-                    // four batches (256 words) per trip: 12 LDS reads in flight, then the arithmetic, then 4 writes.
-                    // Whole trips run without predicates: every lane rewrites its word (unchanged if a literal).
-                    u32 t = 0;
-                    for (; t + 256u <= count; t += 256u) {
-                        u32 *const w = lds + t;
-                        const unsigned short *const pp = pos + t;
-                        u32 v[4], p1[4], p0[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            v[k] = w[lane_v + 64u * k];
-                            p1[k] = pp[lane_v + 64u * k + 1u];
-                            p0[k] = pp[lane_v + 64u * k];
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const u32 len = (p1[k] - p0[k]) & 0xFFFFu;
-                            w[lane_v + 64u * k] = v[k] - 1u >= 0x7FFFFFFEu ? ((v[k] ? kFillOne : kFillZero) | len) : v[k];
-                        }
-                    }
-                    for (u32 j = t + lane_v; j < count; j += 64u) { // last partial trip
-                        const u32 v = lds[j];
-                        const u32 len = ((u32)pos[j + 1] - (u32)pos[j]) & 0xFFFFu;
-                        if (v - 1u >= 0x7FFFFFFEu) lds[j] = (v ? kFillOne : kFillZero) | len;
-                    }
-                }
-            }
-            WAH_STAMP(5);
-
-            // deliver the count; the last worker to arrive publishes the tile's total to the other workgroups
-            // (one 4-byte granule, see resolve_generation) and to the scan wave
-            const u32 q = gen & 3u;
+        // deliver the count (nothing else of this tile is needed to resolve offsets); the last worker to arrive
+        // publishes the tile's total to the other workgroups (one 4-byte granule, see resolve_generation) and to
+        // the scan wave
+        {
+            const u32 q = gen & (kDepth - 1u);
             u32 last = 0;
             if (lane == 0) {
                 lds_st(&s_count[q][wave], count);
@@ -648,46 +681,63 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
                     lds_publish(&s_total_flag[q], gen + 1u);
                 }
             }
-            WAH_STAMP(2);
         }
+        WAH_STAMP(2);
 
-        if (has_prev) {
-            // stream out the previous tile's words (kernels.cu:256 + moveData, kernels.cu:273-280): its offset has
-            // been resolved by the scan wave while this wave classified the current tile
-            const u32 pgen = gen - 1u;
-            const u32 pseg = (tile - stride) * W + wave;
-            if (lds_ld(&s_base_flag[pgen & 1u]) != pgen + 1u) lds_wait(&s_base_flag[pgen & 1u], pgen + 1u, a.ctrl, lane);
-            WAH_STAMP(3);
-            if (pseg < a.n_segments) {
-                const u64 base = uniform64(lds_ld64(&s_base[pgen & 1u])) + uniform32(lds_ld(&s_prefix[pgen & 3u][wave]));
-#ifndef WAH_DIAG
-                if (lane == 0 && a.seg_offsets) a.seg_offsets[pseg] = base;
-#endif
-                if (base < a.out_capacity) {
-                    // descriptor over this segment's slice of the output (clipped to the capacity: words past it
-                    // are dropped by the hardware, and the scan wave has already raised the capacity error)
-                    const u64 room = a.out_capacity - base;
-                    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + base, (room < prev_count ? (u32)room : prev_count) * 4u);
-                    const u32 *src = s_out[pgen & 1u][wave];
-                    const u32 off = lane_v * 4u;
-                    for (u32 t = 0; t < prev_count; t += 256u) { // four LDS reads in flight, then four dense stores
-                        u32 v[4];
+        // room in the ring for this tile's words (every wait here is for an offset published >= 1 iteration ago)
+        while (ok && pend != 0u && (pend == kMaxPending || used + count > kStageWords)) (void)emit_oldest(gen, true, lane_v);
+        if (!ok) break;
+        const bool in_place = pend == 0u; // ring empty: the stage buffer BECOMES the ring, nothing is copied
+        if (in_place) {
+            u32 *const t = stage;
+            stage = ring;
+            ring = t;
+            ring_head = 0;
+        }
+        if (any_fill || !in_place) {
+            // final words (kernels.cu:244-249): fill length = distance between consecutive run ends; written to the
+            // ring behind what is pending (or in place).  Four batches (256 words) per trip: 12 LDS reads in flight,
+            // then the arithmetic, then 4 writes; every lane rewrites its word (unchanged if a literal).
+            const u32 *const src = in_place ? ring : stage;
+            const u32 tail = (ring_head + used) & (kStageWords - 1u);
+            for (u32 t = 0; t < count; t += 256u) {
+                u32 v[4], p1[4], p0[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = src[t + lane_v + 64u * k];
+                for (int k = 0; k < 4; ++k) {
+                    const u32 j = t + lane_v + 64u * k;
+                    v[k] = src[j];
+                    p1[k] = pos[j + 1u];
+                    p0[k] = pos[j];
+                }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(v[k], rsrc, off + 256u * k, t * 4u, 0);
-                    }
+                for (int k = 0; k < 4; ++k) {
+                    const u32 j = t + lane_v + 64u * k;
+                    const u32 len = (p1[k] - p0[k]) & 0xFFFFu;
+                    const u32 w = v[k] - 1u >= 0x7FFFFFFEu ? ((v[k] ? kFillOne : kFillZero) | len) : v[k];
+                    if (j < count) ring[(tail + j) & (kStageWords - 1u)] = w;
                 }
             }
-            // the iteration after next restages this buffer: order these reads before those writes
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            WAH_STAMP(4);
         }
-        if (!has_cur) break;
-        prev_count = count;
+        // push
+        if (pend == 0u) pc0 = count;
+        else if (pend == 1u) pc1 = count;
+        else if (pend == 2u) pc2 = count;
+        else pc3 = count;
+        ++pend;
+        used += count;
+        WAH_STAMP(5);
+
+        // stream out whatever has its offset already
+        while (ok && pend != 0u && emit_oldest(gen + 1u, false, lane_v)) {}
 #ifdef WAH_DIAG
         dg_acc[7] += 1;
 #endif
+    }
+    while (ok && pend != 0u) { // drain
+        u32 lane_v = lane;
+        asm volatile("" : "+v"(lane_v));
+        (void)emit_oldest(gen, true, lane_v);
     }
     WAH_STAMP_FLUSH(a.ctrl);
 #ifdef WAH_DIAG
