@@ -30,17 +30,21 @@ using u64 = uint64_t;
 // Diagnostic build only (make diag): per-phase cycle totals of each workgroup's thread 0, added into the unused
 // tail of the control block.  The product build contains no stamps.
 #ifdef WAH_DIAG
-#define WAH_STAMP_DECL u64 dg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 dg_prev = __builtin_readcyclecounter();
+#define WAH_STAMP_DECL u64 dg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 dg_big[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 dg_prev = __builtin_readcyclecounter();
 #define WAH_STAMP(i)                                      \
     do {                                                  \
         const u64 dg_now = __builtin_readcyclecounter();  \
         dg_acc[i] += dg_now - dg_prev;                    \
+        dg_big[i] += (dg_now - dg_prev) > 4000u;          \
         dg_prev = dg_now;                                 \
     } while (0)
 #define WAH_STAMP_FLUSH(ctrl)                                                                      \
     do {                                                                                           \
         if (threadIdx.x == 0)                                                                      \
-            for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 192) + i, (unsigned long long)dg_acc[i]); \
+            for (int i = 0; i < 8; ++i) {                                                          \
+                atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 192) + i, (unsigned long long)dg_acc[i]); \
+                atomicAdd(reinterpret_cast<unsigned long long *>(ctrl + 192) + 16 + i, (unsigned long long)dg_big[i]); \
+            }                                                                                      \
     } while (0)
 #else
 #define WAH_STAMP_DECL

@@ -21,11 +21,13 @@ for kind in sys.argv[1:] or ["sparse", "dense", "clustered"]:
     comp.status()
     comp.run(d)
     comp.status()
-    acc = comp.workspace[768:768 + 128].view(torch.int64).cpu().tolist()
+    acc = comp.workspace[768:768 + 256].view(torch.int64).cpu().tolist()
     tiles = max(acc[7], 1)
     total = sum(acc[:7])
     print(f"--- {kind}: {tiles} tiles, {total / tiles:.0f} cycles/tile (thread 0 of each workgroup)")
     for nm, v in zip(names[:7], acc[:7]):
         print(f"   {nm:18s} {v / tiles:9.0f} cyc/tile  {100.0 * v / total:5.1f} %")
+    big = acc[16:24]
+    print("   iterations (of thread 0) in which the phase took > 4000 cycles: " + ", ".join(f"{nm.split()[0]} {100.0 * b / tiles:.1f}%" for nm, b in zip(names[:6], big[:6])))
     print(f"   scan wave per tile: wait for counts {acc[8] / tiles:.0f} cyc, resolve {acc[9] / tiles:.0f} cyc")
     del comp, d
