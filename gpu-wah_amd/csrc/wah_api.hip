@@ -271,11 +271,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         }
         // the sums kernel works on workgroup tiles of kSumTilesPerGroup expand tiles
         const uint64_t wg_tiles = ceil_div(l.n_tiles, (uint64_t)wah::kSumTilesPerGroup);
-        uint64_t grid64 = (uint64_t)resident < wg_tiles ? (uint64_t)resident : (wg_tiles ? wg_tiles : 1);
-        if (const char *dbg = std::getenv("WAH_SUMS_GRID")) {
-            const uint64_t g = std::strtoull(dbg, nullptr, 10);
-            if (g >= 1 && g < grid64) grid64 = g;
-        }
+        const uint64_t grid64 = (uint64_t)resident < wg_tiles ? (uint64_t)resident : (wg_tiles ? wg_tiles : 1);
         const uint64_t generations = (wg_tiles + grid64 - 1) / grid64;
         const size_t used = round256(l.desc_off + (generations * ((grid64 + 3) & ~3ull) + 8) * sizeof(uint32_t));
         e = hipMemsetAsync(ws, 0, used < l.zero_bytes ? used : l.zero_bytes, s);

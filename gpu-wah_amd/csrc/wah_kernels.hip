@@ -199,17 +199,19 @@ __device__ __forceinline__ u64 resolve_generation(const u32 *gdesc, u32 gen, u32
 // ===========================================================================
 // compress
 //
-// Workgroup = W worker wavefronts + 1 scan wavefront, persistent, ONE barrier per iteration.
+// Workgroup = W worker wavefronts + 1 scan wavefront, persistent, no barrier after start-up.
 //   worker w : owns segment tile*W + w.  Per iteration g: the 4 x 16-byte loads of its segment were issued an
-//              iteration earlier (software prefetch); it stages them in one of its two private 4 KiB LDS buffers,
-//              issues the next tile's loads, classifies, compacts the run-end words in place, turns them into
-//              final WAH words (fill length = distance between consecutive run ends) -- none of which needs the
-//              output offset -- and leaves them in LDS.  After the barrier it streams out the PREVIOUS tile's
-//              words (other buffer) with dense 256-byte stores at the offset resolved meanwhile.
-//   scan wave: never touches bitmap data, so its memory queue only holds granule traffic.  After the barrier it
-//              publishes the tile's word count; during the workers' next classify it resolves the offset.
-// Resolution of tile g thus overlaps classification of tile g+1: a workgroup only stalls when a predecessor is a
-// whole iteration late, instead of every generation waiting for its slowest member.
+//              iteration earlier (software prefetch); it stages them in its private 4 KiB STAGE buffer, issues the
+//              next tile's loads, classifies, compacts the run-end words in place, delivers their count, and turns
+//              them into final WAH words (fill length = distance between consecutive run ends) written to its
+//              private 4 KiB RING behind the words of earlier tiles that still wait for their output offset.
+//              Whenever the offset of the oldest tile in the ring is known it is streamed out with dense 256-byte
+//              stores (kernels.cu:256 + moveData).
+//   scan wave: never touches bitmap data, so its memory queue only holds granule traffic.  Takes the tile's word
+//              count from the last worker to deliver, resolves the tile's offset with the one-hop generation scan
+//              above and hands it to the workers through LDS.
+// Offsets are therefore needed two to four iterations after the counts were published (one for incompressible
+// data, where a tile fills the ring), which absorbs the resolve latency and the jitter between 256 workgroups.
 // ===========================================================================
 constexpr u32 kStageWords = 1024; // staged segment (992 words + look-ahead) / compacted output words (<= 1024), aliased
 constexpr u32 kOutWords = kStageWords + 4; // + one dump dword (non-end lanes), kept 16-byte aligned
