@@ -18,6 +18,7 @@ The directory name contains a hyphen, so import it with
 or through the `gpu_wah_amd` shim module at the repository root.
 """
 from . import columns  # noqa: F401
+from . import report  # noqa: F401
 from .api import (  # noqa: F401
     WahError,
     Timings,

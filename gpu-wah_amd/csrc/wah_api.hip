@@ -310,6 +310,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         x.tile_base = reinterpret_cast<const uint64_t *>(ws + l.base_off);
         x.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
         x.aligned16 = aligned16(d_comp) ? 1 : 0;
+        x.parts = 1; // the launcher decides
         e = wah::launch_decode_expand(x, l.n_tiles, s);
         if (e != hipSuccess) {
             set_err("decode expand kernel launch", e);

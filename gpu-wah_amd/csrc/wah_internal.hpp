@@ -79,6 +79,7 @@ struct ExpandArgs {
     const uint64_t *tile_base;
     uint32_t *ctrl;
     int aligned16;
+    uint32_t parts; // workgroups that share one tile's output segments (set by the launcher)
 };
 
 // launchers (wah_kernels.hip)

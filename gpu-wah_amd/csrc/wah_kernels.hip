@@ -1196,12 +1196,14 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
-    const u32 tile = blockIdx.x;
+    // a stream of few tiles (highly compressed data) expands to many segments per tile: `parts` workgroups share a tile
+    const u32 tile = blockIdx.x / a.parts;
+    const u32 part = blockIdx.x % a.parts;
     const u64 tile_w0 = (u64)tile * kScanTileWords;
     const u64 groups = a.info[1];
     const u64 out_words = a.info[0];
     if (out_words > a.out_capacity) {
-        if (threadIdx.x == 0 && tile == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
         return;
     }
 
@@ -1256,7 +1258,7 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
 
     unsigned char *flag = s_flag[wave];
     const bool tame = total < (1ull << 31); // wave-uniform: positions inside this tile fit 32 bits
-    for (u64 seg = k_begin + wave; seg < k_end; seg += kExpandWaves) {
+    for (u64 seg = k_begin + wave + (u64)kExpandWaves * part; seg < k_end; seg += (u64)kExpandWaves * a.parts) {
         if (tame) {
             const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
             expand_segment_tame(a, s_words, s_coarse32, flag, tile_w0, (u32)(seg * kSegGroups - base), nvalid, out_words, seg, lane);
@@ -1383,9 +1385,21 @@ hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_decode_expand(const ExpandArgs &a, u64 n_tiles, hipStream_t s) {
+hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s) {
     if (n_tiles == 0) return hipSuccess;
-    hipLaunchKernelGGL(decode_expand_kernel, dim3((unsigned)n_tiles), dim3(kExpandThreads), 0, s, a);
+    // One workgroup per tile fills the chip when the stream is long.  A short stream that expands a lot (highly
+    // compressed bitmaps: thousands of output segments per tile) is shared out: `parts` workgroups per tile, each
+    // taking every parts-th group of kExpandWaves segments.  The true output size is only known on the device; the
+    // capacity bounds it, and a part with nothing to do costs one 16 KiB tile read.
+    ExpandArgs a = a0;
+    const u64 want = 4096; // workgroups: 256 CUs x 7 resident x ~2
+    const u64 segs_per_tile = a.out_capacity / kSegWords / n_tiles;
+    u64 parts = (want + n_tiles - 1) / n_tiles;
+    if (parts > segs_per_tile / (2 * kExpandWaves)) parts = segs_per_tile / (2 * kExpandWaves);
+    if (parts < 1) parts = 1;
+    if (parts > 1024) parts = 1024;
+    a.parts = (u32)parts;
+    hipLaunchKernelGGL(decode_expand_kernel, dim3((unsigned)(n_tiles * parts)), dim3(kExpandThreads), 0, s, a);
     return hipGetLastError();
 }
 
