@@ -41,11 +41,10 @@ CompressLayout compress_layout(uint64_t n_words) {
     l.n_tiles = ceil_div(l.n_segments, (uint64_t)wah::compress_workers());
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
-    // granule tables (see the scan wave of compress_kernel): per generation round_up(G, 16) tile granules and
-    // round_up(ceil(G / 16), 16) group granules for G resident workgroups (G is only known after the census):
-    // at most 32 granules per tile
+    // generation rows: rows of round_up(G, 4) granules for G resident workgroups (G is only known after the
+    // census): at most n_tiles + 3 * generations + 3 <= 4 * n_tiles + 8 granules
     l.block_off = l.desc_off;
-    l.total = round256(l.desc_off + (32 * l.n_tiles + 32) * sizeof(uint32_t));
+    l.total = round256(l.desc_off + (4 * l.n_tiles + 8) * sizeof(uint32_t));
     return l;
 }
 
@@ -191,8 +190,7 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
     }
     const uint64_t grid64 = (uint64_t)resident < l.n_tiles ? (uint64_t)resident : (l.n_tiles ? l.n_tiles : 1);
     const uint64_t generations = (l.n_tiles + grid64 - 1) / grid64;
-    const uint64_t row_granules = ((grid64 + 15) & ~15ull) + ((((grid64 + 15) >> 4) + 15) & ~15ull);
-    const size_t used = round256(l.desc_off + (generations * row_granules + 16) * sizeof(uint32_t));
+    const size_t used = round256(l.desc_off + (generations * ((grid64 + 3) & ~3ull) + 8) * sizeof(uint32_t));
     hipError_t e = hipMemsetAsync(ws, 0, used < l.total ? used : l.total, s);
     if (e != hipSuccess) {
         set_err("hipMemsetAsync", e);
@@ -222,7 +220,6 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
     a.seg_offsets = d_segment_offsets;
     a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
     a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
-    a.n_gens = (uint32_t)generations;
     a.census = 0;
     const int grid = (int)grid64;
     e = wah::launch_compress(workers, a, grid, s);

@@ -53,8 +53,7 @@ struct CompressArgs {
     uint64_t *out_words;   // device scalar: C
     uint64_t *seg_offsets; // optional, n_segments + 1 entries
     uint32_t *ctrl;        // kCtlWords
-    uint32_t *gen_desc;    // granule table: one 4-byte granule per tile (see granule_ptr)
-    uint32_t n_gens;       // its number of generations = ceil(n_tiles / grid)
+    uint32_t *gen_desc;    // generation rows: one 4-byte granule per tile (see resolve_generation)
     int census;            // 1: residency census only (see compress_grid)
 };
 

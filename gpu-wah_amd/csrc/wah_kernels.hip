@@ -500,92 +500,14 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
         __builtin_amdgcn_s_setprio(2);
     if (!worker) {
         // ---------------- scan wave: resolve output offsets, tile after tile, as the counts come in ------------
-        // Two-level generation scan.  The granule tables are read at agent scope, i.e. from the memory side, by every
-        // workgroup, and that traffic is expensive (measured: a scan in which every workgroup read whole rows of tile
-        // granules lost 20 % of the kernel per extra row polled).  So the slots of a generation form groups of 16:
-        //   tile granule  (gen, slot)  : words of the tile, published by the tile's last worker (one 4-byte word)
-        //   group granule (gen, group) : words of the group's 16 tiles, published by the scan wave of the group's
-        //                                last slot, which needs the other 15 for its own offset anyway
-        // and the offset of tile (gen, 16 G + m) = [all earlier generations] + [groups below G] + [tiles below m in G]
-        // costs three 64-byte reads per poll (own group's tiles, this generation's groups, the previous
-        // generation's groups for its total) instead of one or two whole rows.  The price is a second hop (tile ->
-        // group -> reader), which the workers' ring of pending output absorbs.
-        const u32 my_gens = arrival < a.n_tiles ? (a.n_tiles - arrival + stride - 1u) / stride : 0u;
-        const u32 n_groups = (stride + 15u) >> 4;
-        const u32 tile_stride = (stride + 15u) & ~15u;       // granules per generation in the tile table
-        const u32 group_stride = (n_groups + 15u) & ~15u;    // ... and in the group table behind it
-        u32 *const tile_tab = a.gen_desc;
-        u32 *const group_tab = a.gen_desc + (u64)a.n_gens * tile_stride;
-        const u32 my_group = arrival >> 4, my_member = arrival & 15u;
-        const u32 group_first = my_group << 4;
-        const bool leader = my_member == 15u || arrival == stride - 1u; // last slot of its group
-        u64 acc = 0; // words of all earlier generations
-        for (u32 gen = 0; gen < my_gens; ++gen) {
+        GenScan scan = {0, 0, 0};
+        u32 gen = 0;
+        for (u32 tile = arrival; tile < a.n_tiles; tile += stride, ++gen) {
             const u32 q = gen & (kDepth - 1u);
             if (!lds_wait(&s_total_flag[q], gen + 1u, a.ctrl, lane)) break;
             const u32 aggregate = uniform32(lds_ld(&s_total[q]));
-            __builtin_amdgcn_s_setprio(2);
             WAH_STAMP(0);
-            const u32 tile = arrival + gen * stride;
-            // generations in flight when this one is: everybody of the previous one has at least started, so its
-            // last generation may be short
-            const u32 prev_slots = stride; // the previous generation is always complete
-            (void)prev_slots;
-            bool need_members = my_member > 0u, need_groups = my_group > 0u, need_prev = gen > 0u, need_publish = leader;
-            u32 members = 0, groups = 0, spins = 0;
-            bool failed = false;
-            while (need_members || need_groups || need_prev || need_publish) {
-                u32 vm = kGenValid, vg = kGenValid, vp = kGenValid;
-                if (need_members && lane < my_member)
-                    vm = __hip_atomic_load(tile_tab + (u64)gen * tile_stride + group_first + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bool bad_g = false, bad_p = false;
-                u32 sum_g = 0, sum_p = 0;
-                for (u32 g0 = lane; g0 < n_groups; g0 += 64u) { // one trip for up to 1024 workgroups
-                    if (need_groups && g0 < my_group) {
-                        vg = __hip_atomic_load(group_tab + (u64)gen * group_stride + g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        bad_g |= !(vg & kGenValid);
-                        sum_g += vg & ~kGenValid;
-                    }
-                    if (need_prev) {
-                        vp = __hip_atomic_load(group_tab + (u64)(gen - 1u) * group_stride + g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        bad_p |= !(vp & kGenValid);
-                        sum_p += vp & ~kGenValid;
-                    }
-                }
-                bool progressed = false;
-                if (need_members && !__any(!(vm & kGenValid))) {
-                    members = uniform32(wave_sum32(lane < my_member ? vm & ~kGenValid : 0u));
-                    need_members = false;
-                    progressed = true;
-                }
-                if (need_publish && !need_members) { // the group's total: its 15 lower tiles + mine
-                    if (lane == 0)
-                        __hip_atomic_store(group_tab + (u64)gen * group_stride + my_group, kGenValid | (members + aggregate),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    need_publish = false;
-                    progressed = true;
-                }
-                if (need_groups && !__any(bad_g)) {
-                    groups = uniform32(wave_sum32(sum_g));
-                    need_groups = false;
-                    progressed = true;
-                }
-                if (need_prev && !__any(bad_p)) {
-                    acc += uniform32(wave_sum32(sum_p));
-                    need_prev = false;
-                    progressed = true;
-                }
-                if (!progressed) {
-                    if (++spins > kMaxSpins) {
-                        if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
-                        failed = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            if (failed) break;
-            const u64 excl = acc + groups + members;
+            const u64 excl = resolve_generation(a.gen_desc, gen, arrival, stride, row_stride, aggregate, scan, lane, a.ctrl);
             WAH_STAMP(1);
 #ifdef WAH_DIAG
             if (lane == 0 && a.seg_offsets) {
@@ -759,8 +681,7 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
 #ifdef WAH_DIAG
                     if (a.seg_offsets) a.seg_offsets[(u64)tile * 4 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
-                    __hip_atomic_store(a.gen_desc + (u64)gen * ((stride + 15u) & ~15u) + arrival, kGenValid | total, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                    publish_generation(a.gen_desc, gen, arrival, row_stride, total);
                     lds_st(&s_arrived[q], 0u);
                     lds_st(&s_total[q], total);
                     lds_publish(&s_total_flag[q], gen + 1u);
