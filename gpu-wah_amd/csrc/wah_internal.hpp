@@ -23,6 +23,7 @@ constexpr uint32_t kSteps = 16; // 64 groups (one wavefront) per step
 constexpr uint32_t kCtlStart = 0;        // arrival ticket: order in which workgroups start running
 constexpr uint32_t kCtlError = 160;      // sticky error bits
 constexpr uint32_t kCtlCensus = 161;     // census mode: workgroups resident together
+constexpr uint32_t kCtlFlags = 162;      // decode: bit 0 = the stream contains fill words of count 0
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
 constexpr uint32_t kErrTimeout = 1u;     // a bounded wait expired
 constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity

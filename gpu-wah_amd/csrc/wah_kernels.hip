@@ -92,6 +92,17 @@ __device__ __forceinline__ u32 wave_scan_incl32(u32 v) {
     return v;
 }
 
+// inclusive prefix MAXIMUM of a u32 across the 64 lanes, same DPP pattern (missing sources read as 0)
+__device__ __forceinline__ u32 wave_scan_max32(u32 v) {
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false));
+    v = max(v, (u32)__builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false));
+    return v;
+}
+
 // Values read back from LDS are wave-uniform here by construction; readfirstlane tells the compiler so, which
 // keeps everything derived from them (segment numbers, masks, offsets, branches) on the scalar unit.
 __device__ __forceinline__ u32 uniform32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
@@ -910,6 +921,12 @@ __global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(con
 
     // worker waves: stream one expand tile per iteration, sum the group counts (getCounts, kernels.cu:291-309)
     uint4 pre[4];
+    // A fill word of count 0 expands to nothing; the reference decoder steps over it (kernels.cu:332-354).  The
+    // expand kernel's rank arithmetic assumes that every word owns at least one group, so the stream is checked
+    // here and expand takes its general (slower) route when one is found.  `pre_whole`: the prefetched round consists
+    // of real words only (no padding past the end, which is written as empty fills).
+    bool saw_empty = false, pre_whole = true;
+    u32 n_min = 1;
     // round `rd` (0..3) of expand tile `et`: 1024 words as four fully coalesced 1 KiB loads (order is irrelevant)
     auto load_round = [&](u32 et, u32 rd) {
         const u64 w0 = (u64)et * kScanTileWords + (u64)rd * 1024u;
@@ -917,12 +934,15 @@ __global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(con
             const uint4 *src = reinterpret_cast<const uint4 *>(a.comp + w0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) pre[k] = src[k * 64 + (int)lane];
+            pre_whole = true;
         } else {
             u32 t[16];
+            pre_whole = false;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const u64 i = w0 + (u64)(k / 4) * 256u + (u64)lane * 4u + (u64)(k % 4);
                 t[k] = i < a.c_words ? a.comp[i] : 0x80000000u; // past the end: a fill of zero groups
+                saw_empty |= i < a.c_words && word_groups(t[k]) == 0u;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) pre[k] = make_uint4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
@@ -938,14 +958,20 @@ __global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(con
             uint4 cur[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) cur[k] = pre[k];
+            const bool cur_whole = pre_whole;
             // rolling prefetch: next round of this tile, or round 0 of this wave's next tile
             if (rd < 3)
                 load_round(et, rd + 1);
             else if (wt + stride < n_wg_tiles)
                 load_round((wt + stride) * (u32)kSumWorkers + wave, 0);
+            u32 round_min = 1;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) // four counts of < 2^30 each fit 32 bits; words past the end are empty fills
-                mine += (u64)(word_groups(cur[k].x) + word_groups(cur[k].y) + word_groups(cur[k].z) + word_groups(cur[k].w));
+            for (int k = 0; k < 4; ++k) { // four counts of < 2^30 each fit 32 bits; words past the end are empty fills
+                const u32 nx = word_groups(cur[k].x), ny = word_groups(cur[k].y), nz = word_groups(cur[k].z), nw = word_groups(cur[k].w);
+                mine += (u64)(nx + ny + nz + nw);
+                round_min = min(min(round_min, min(nx, ny)), min(nz, nw));
+            }
+            if (cur_whole) n_min = min(n_min, round_min);
         }
         const u64 wave_total = uniform64(wave_sum(mine));
         const u32 q = gen & 3u;
@@ -977,6 +1003,7 @@ __global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(con
             }
         }
     }
+    if (__any(saw_empty || n_min == 0u) && lane == 0) atomicOr(a.ctrl + kCtlFlags, 1u);
 }
 
 // ---------------------------------------------------------------------------
@@ -1110,6 +1137,59 @@ __device__ __forceinline__ void expand_segment_general(const ExpandArgs &a, cons
         return;
     }
     expand_emit(a, s_words, flag, tile_w0, first_word, nvalid, out_words, seg, false, lane);
+}
+
+// ---- one output segment, streams with fill words of count 0 (foreign streams only; the reference decoder steps over
+// such words, kernels.cu:332-354).  The rank arithmetic of the routines above assumes that consecutive contributing
+// words are consecutive in the stream, which an empty word in between breaks.  Here every contributing word writes
+// its own index at the group it starts at, and a group's source is the last index written at or before it (a
+// running maximum: indices grow with position).  One wavefront, 4 KiB of LDS (`src`), any counts. ----------------
+__device__ __forceinline__ void expand_segment_with_empties(const ExpandArgs &a, const u32 *s_words, const u64 *s_coarse,
+                                                            u32 *src, u64 tile_w0, u64 base, u64 groups, u64 out_words,
+                                                            u64 seg, u32 lane) {
+    const u64 target = seg * kSegGroups - base; // tile-relative position of the segment's first group
+    const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
+    const u64 c = lane < kCoarse ? s_coarse[lane] : ~0ull;
+    const u32 bucket = (u32)__popcll(__ballot(c <= target)) - 1u;
+    const u64 drop = target - uniform64(s_coarse[bucket]); // groups of the bucket in front of the segment
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<uint4 *>(src)[k * 64 + (int)lane] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    u64 seen = 0; // groups of the words looked at so far, from the bucket start
+    u32 wi = bucket * 64u;
+    while (seen < drop + nvalid && tile_w0 + wi < a.c_words) {
+        const u32 idx = wi + lane;
+        const bool in = tile_w0 + idx < a.c_words;
+        const u32 n = in ? word_groups(tile_word(s_words, a, tile_w0, idx)) : 0u;
+        const u64 incl_n = wave_scan_incl((u64)n, lane);
+        const u64 lo = seen + (incl_n - n), hi = seen + incl_n; // the word covers [lo, hi) from the bucket start
+        if (n != 0u && hi > drop && lo < drop + nvalid) src[lo > drop ? (u32)(lo - drop) : 0u] = idx + 1u;
+        seen += uniform64(__shfl(incl_n, 63));
+        wi += 64u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (seen < drop + nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
+        if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+        return;
+    }
+    const u64 seg_w0 = seg * kSegWords;
+    const u32 seg_words = out_words > seg_w0 ? (u32)(out_words - seg_w0 < kSegWords ? out_words - seg_w0 : kSegWords) : 0u;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + seg_w0, seg_words * 4u); // stores past the end are dropped
+    const u32 o = lane & 31u;
+    const u32 up = 31u - ((lane - 1u) & 31u);
+    const u32 soff = o != 31u ? (lane - (lane >> 5)) * 4u : 0xFFFFF000u;
+    u32 carry = 0;
+    for (u32 s = 0; s < kSteps; ++s) {
+        const u32 m = max(wave_scan_max32(src[64u * s + lane]), carry); // index + 1 of the word my group belongs to
+        carry = (u32)__builtin_amdgcn_readlane((int)m, 63);
+        const u32 src_word = tile_word(s_words, a, tile_w0, m ? m - 1u : 0u);
+        const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
+        u32 grp = (int)src_word < 0 ? fill_val : src_word;
+        if (64u * s + lane >= nvalid) grp = 0u;
+        const u32 hi_part = (u32)__builtin_amdgcn_mov_dpp((int)(grp << up), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+        __builtin_amdgcn_raw_buffer_store_b32((grp >> o) | hi_part, rsrc, soff + 248u * s, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
 // ---- one output segment, fast version: the tile expands to fewer than 2^31 groups, so every position relative to the
@@ -1256,6 +1336,16 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
     u64 k_end = (base + total + kSegGroups - 1) / kSegGroups;
     if (k_end > n_seg) k_end = n_seg;
 
+    if (a.ctrl[kCtlFlags] & 1u) {
+        // the stream contains fill words of count 0 (found by the sums pass): general route, one wavefront per
+        // workgroup, the four flag areas together hold its 1024-entry index map
+        static_assert(sizeof(s_flag) >= kSegGroups * sizeof(u32), "index map must fit the flag areas");
+        if (wave == 0)
+            for (u64 seg = k_begin + part; seg < k_end; seg += a.parts)
+                expand_segment_with_empties(a, s_words, s_coarse, reinterpret_cast<u32 *>(&s_flag[0][0]), tile_w0, base, groups,
+                                            out_words, seg, lane);
+        return;
+    }
     unsigned char *flag = s_flag[wave];
     const bool tame = total < (1ull << 31); // wave-uniform: positions inside this tile fit 32 bits
     for (u64 seg = k_begin + wave + (u64)kExpandWaves * part; seg < k_end; seg += (u64)kExpandWaves * a.parts) {

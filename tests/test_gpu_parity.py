@@ -150,6 +150,48 @@ def test_decoder_accepts_foreign_streams(wah, oracle):
         assert np.array_equal(gd, want)
 
 
+# ---------------------------------------------------------------- decoder: tile / generation boundaries
+def test_decode_tile_boundaries_and_odd_streams(wah, oracle):
+    """Ragged sizes around the decoder's tile (4096 words) and tile-group boundaries, count-0 fills, tiles of fills
+    only, thousands of output segments per tile, capacity errors."""
+    rng = np.random.default_rng(77)
+    # ragged sizes around tile (4096 words) and look-back group (64 tiles) boundaries, several densities
+    for n in (1, 31, 992, 4096 * 3 + 5, 992 * 700 + 13, 4096 * 64 * 3 + 4097):
+        for p in (0.5, 0.05, 2.0**-9):
+            data = oracle.gen_uniform(n, int(rng.integers(1 << 30)), p)
+            comp = oracle.compress(data)
+            want = oracle.decompress(comp)
+            got = _host(wah.decompress_device(_dev(comp), len(want)))
+            assert np.array_equal(got, want), (n, p)
+    # foreign streams: count 0, giant fills (tile totals >= 2^31), fills straddling segments, unmerged fills
+    streams = [
+        np.array([0x80000000 | 5000, 0x12345, 0xC0000000 | 3000, 0x80000001, 0x7FFFFFFE], np.uint32),
+        np.array([0x80000000, 0xC0000000, 7, 0x80000000 | 40, 0xC0000000, 9], np.uint32),
+        np.array([3] * 5000 + [0x80000000 | 100] * 4000 + [0xC0000000 | 7] * 3000 + [0x80000000] * 500 + [5], np.uint32),
+        np.concatenate([np.full(9000, 0x80000000 | 3, np.uint32), np.arange(1, 9001, dtype=np.uint32)]),
+    ]
+    for st in streams:
+        want = oracle.decompress(st)
+        got = _host(wah.decompress_device(_dev(st), len(want) + 3))
+        assert np.array_equal(got[: len(want)], want)
+    # clustered: thousands of output segments per tile
+    data = oracle.gen_clustered(992 * 3000 + 17, 99)
+    comp = oracle.compress(data)
+    got = _host(wah.decompress_device(_dev(comp), data.size + 1))
+    assert np.array_equal(got[: data.size], data)
+    # capacity below the decoded size: reported, nothing written past the capacity
+    import torch
+    data = oracle.gen_uniform(992 * 300, 5, 0.5)
+    comp = oracle.compress(data)
+    dec = wah.DeviceDecompressor(len(comp), 5000)
+    guard = torch.full((5000 + 4096,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    dec.out = guard[:5000]
+    dec.run(_dev(comp))
+    with pytest.raises(wah.WahError):
+        dec.status()
+    assert bool((guard[5000:] == 0x5A5A5A5A).all())
+
+
 # ---------------------------------------------------------------- API behaviour
 def test_reusable_workspace_and_indexed_output(wah, oracle):
     """Same DeviceCompressor run repeatedly (control block re-zeroed every launch) + the segment index."""

@@ -189,3 +189,19 @@ def test_generators_are_stable(oracle):
     flips = np.count_nonzero(bits[1:] != bits[:-1])
     mean_run = bits.size / (flips + 1)
     assert 3300 < mean_run < 5000
+
+
+def test_decoder_steps_over_empty_fills(oracle):
+    """A fill word of count 0 expands to nothing (decompressWords' loop runs zero times, kernels.cu:346-348); the C
+    oracle and the bit-at-a-time Python statement agree on such foreign streams."""
+    from tests import _oracle
+
+    streams = [
+        [0x80000000, 0xC0000000, 7, 0x80000000 | 40, 0xC0000000, 9],
+        [0x80000000] * 5 + [0x7FFFFFFE, 0xC0000000 | 2] + [0xC0000000] * 3 + [1],
+        [5, 0x80000000, 0x80000000, 6, 0xC0000000, 0xC0000001],
+    ]
+    for st in streams:
+        a = np.array(st, np.uint32)
+        assert np.array_equal(oracle.decompress(a), _oracle.py_decompress(a))
+        assert oracle.decoded_groups(a) == sum((w & 0x3FFFFFFF) if w & 0x80000000 else 1 for w in st)
