@@ -192,6 +192,66 @@ def test_decode_tile_boundaries_and_odd_streams(wah, oracle):
     assert bool((guard[5000:] == 0x5A5A5A5A).all())
 
 
+def _random_foreign_stream(rng, n_words, max_groups):
+    """Anything the reference decoder accepts: literals of any 31-bit value (0 and 0x7FFFFFFF included), fills of any
+    count -- 0, 1, around the segment length, far beyond it -- in any order, unmerged."""
+    kinds = rng.integers(0, 10, n_words)
+    lit = rng.integers(0, 1 << 31, n_words, dtype=np.uint64).astype(np.uint32)
+    lit[rng.random(n_words) < 0.1] = 0
+    lit[rng.random(n_words) < 0.1] = 0x7FFFFFFF
+    pool = np.array([0, 0, 1, 1, 2, 3, 30, 31, 32, 33, 63, 64, 65, 1000, 1023, 1024, 1025, 2047, 2048, 5000, 1 << 15, (1 << 16) + 1],
+                    np.uint32)
+    cnt = pool[rng.integers(0, len(pool), n_words)]
+    bit = rng.integers(0, 2, n_words).astype(np.uint32)
+    fill = np.uint32(0x80000000) | (bit << np.uint32(30)) | cnt
+    st = np.where(kinds < 6, lit, fill).astype(np.uint32)
+    # keep the expansion bounded: cut where the running group count would exceed max_groups
+    groups = np.where(st & 0x80000000, st & 0x3FFFFFFF, 1).astype(np.int64)
+    keep = int(np.searchsorted(np.cumsum(groups), max_groups, side="right"))
+    return st[: max(keep, 1)]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_decoder_fuzz_foreign_streams(wah, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    n_words = int(rng.choice([50, 3000, 4096 * 2 + 3, 4096 * 9 + 100, 4096 * 70]))
+    st = _random_foreign_stream(rng, n_words, max_groups=24_000_000)
+    want = oracle.decompress(st)
+    got = _host(wah.decompress_device(_dev(st), len(want) + 2))
+    assert len(got) == len(want) and np.array_equal(got, want), (seed, n_words)
+    # the same without empty fills: the fast routes
+    st2 = st[~(((st & 0x80000000) != 0) & ((st & 0x3FFFFFFF) == 0))]
+    want2 = oracle.decompress(st2)
+    got2 = _host(wah.decompress_device(_dev(st2), len(want2) + 2))
+    assert np.array_equal(got2, want2), (seed, n_words)
+    assert np.array_equal(want2, want)  # empty fills change nothing
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_compress_fuzz_structured(wah, oracle, seed):
+    """Random run structures: run lengths drawn around the lane, step, segment and tile sizes, literals in between."""
+    rng = np.random.default_rng(2000 + seed)
+    n_bits = int(rng.choice([31 * 64 * 7, 992 * 32 * 37 + 5 * 32, 992 * 32 * 15 * 9 + 992 * 32 * 3 + 64]))
+    bits = np.zeros(n_bits, np.uint8)
+    pos = 0
+    lengths = np.array([1, 2, 30, 31, 32, 33, 61, 62, 63, 64, 65, 1983, 1984, 1985, 31 * 1024 - 1, 31 * 1024, 31 * 1024 + 1, 31 * 1024 * 3])
+    while pos < n_bits:
+        ln = int(lengths[rng.integers(0, len(lengths))]) + int(rng.integers(0, 3))
+        kind = rng.integers(0, 3)
+        if kind == 2:
+            ln = min(ln, 200)
+            bits[pos: pos + ln] = rng.integers(0, 2, min(ln, n_bits - pos))
+        else:
+            bits[pos: pos + ln] = kind
+        pos += ln
+    data = np.packbits(bits[: (n_bits // 32) * 32].reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+    want = oracle.compress(data)
+    got = _host(wah.compress_device(_dev(data)))
+    assert got.shape == want.shape and np.array_equal(got, want), seed
+    back = _host(wah.decompress_device(_dev(want), data.size + 1))
+    assert np.array_equal(back[: data.size], data), seed
+
+
 # ---------------------------------------------------------------- API behaviour
 def test_reusable_workspace_and_indexed_output(wah, oracle):
     """Same DeviceCompressor run repeatedly (control block re-zeroed every launch) + the segment index."""
@@ -314,6 +374,14 @@ def test_config4_dense_1gib(wah, oracle):
     d_in = wah.gen_uniform_device(n, 1337, 0.5)
     C = _full_size_case(wah, oracle, d_in, n, sample_segments=2048)
     assert abs(C - (32 * n + 30) // 31) <= 2
+
+
+def test_beyond_2_31_words(wah, oracle):
+    """the reference is limited to dataSize < 2^31 words (int indices).  Here sizes, offsets and word
+    indices are 64-bit: an 8 GiB + bitmap (2^31 + 992 * 5 + 3 words) round-trips, and its prefix matches the oracle."""
+    n = (1 << 31) + 992 * 5 + 3
+    d_in = wah.gen_uniform_device(n, 4242, 0.01)
+    _full_size_case(wah, oracle, d_in, n, sample_segments=2048, expect_ratio=(0.47, 0.49))
 
 
 def test_config5_columns(wah, oracle):
