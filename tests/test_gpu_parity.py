@@ -150,10 +150,10 @@ def test_decoder_accepts_foreign_streams(wah, oracle):
         assert np.array_equal(gd, want)
 
 
-# ---------------------------------------------------------------- decoder: tile / generation boundaries
+# ---------------------------------------------------------------- decoder: tile boundaries, odd streams
 def test_decode_tile_boundaries_and_odd_streams(wah, oracle):
-    """Ragged sizes around the decoder's tile (4096 words) and tile-group boundaries, count-0 fills, tiles of fills
-    only, thousands of output segments per tile, capacity errors."""
+    """Ragged sizes around the decoder's tile (4096 words) boundaries, count-0 fills, tiles of fills only, thousands
+    of output segments per tile, capacity errors."""
     rng = np.random.default_rng(77)
     # ragged sizes around tile (4096 words) and look-back group (64 tiles) boundaries, several densities
     for n in (1, 31, 992, 4096 * 3 + 5, 992 * 700 + 13, 4096 * 64 * 3 + 4097):
