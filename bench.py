@@ -53,6 +53,7 @@ def parse():
                     help="bitmap size in 32-bit words (default 268435200 = 270600 whole segments = 1 GiB - 1 KiB; "
                          "columns: 33554400 = 128 MiB)")
     ap.add_argument("--columns", type=int, default=None, help="columns workload: total number of columns (default 64 per GPU)")
+    ap.add_argument("--per-column-launches", action="store_true", help="columns workload: one launch per column instead of one per step")
     ap.add_argument("--cpu-sample-mib", type=int, default=256, help="size of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1337)
@@ -154,19 +155,34 @@ def main():
         n = args.words or 33554400
         n_columns = args.columns or 64 * world
         mine = wah.columns.shard_columns(n_columns, rank, world)
-        cols = [wah.columns.make_column(wah, wah.columns.column_spec(c, n, args.seed), dev) for c in mine]
-        comp = wah.DeviceCompressor(n, device=dev)
-        sizes = []
+        specs = [wah.columns.column_spec(c, n, args.seed) for c in mine]
+        batched = n % wah.columns.SEGMENT_WORDS == 0 and not args.per_column_launches
+        if batched:
+            # the rank's columns as one [columns, n] matrix: ONE launch compresses them all (whole 992-word segments,
+            # so the result is the columns' streams back to back; the segment index gives the column boundaries)
+            matrix = wah.columns.make_column_matrix(wah, specs, dev)
+            comp = wah.DeviceCompressor(matrix.numel(), device=dev, indexed=True)
 
-        def step():
-            sizes[:] = wah.columns.compress_columns(comp, cols)
+            def step():
+                wah.columns.compress_column_matrix(comp, matrix, wait=False)
 
-        step()
-        comp.status()
-        c_words_rank = float(sum(int(s.item()) for s in sizes))
+            step()
+            comp.status()
+            c_words_rank = float(comp.count.item())
+        else:
+            cols = [wah.columns.make_column(wah, sp, dev) for sp in specs]
+            comp = wah.DeviceCompressor(n, device=dev)
+            sizes = []
+
+            def step():
+                sizes[:] = wah.columns.compress_columns(comp, cols)
+
+            step()
+            comp.status()
+            c_words_rank = float(sum(int(s.item()) for s in sizes))
         elapsed = timed_steps(step, args.steps, args.warmup, dist, dev, red_dev)
         comp.status()
-        stats = torch.tensor([4.0 * n * len(cols), c_words_rank], dtype=torch.float64, device=red_dev)
+        stats = torch.tensor([4.0 * n * len(specs), c_words_rank], dtype=torch.float64, device=red_dev)
         if dist is not None:
             dist.all_reduce(stats)
         if rank == 0:
@@ -177,7 +193,8 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                 "config": {"workload": desc, "words_per_column": n, "columns": n_columns,
-                           "columns_per_gpu": len(cols), "seed": args.seed,
+                           "columns_per_gpu": len(specs), "seed": args.seed,
+                           "launches_per_step": 1 if batched else len(specs),
                            "parallelism": f"column-shard x{world}, no collective"},
                 "compression_ratio_C_over_N": round(c_words_job * 4.0 / in_bytes_job, 6),
             }

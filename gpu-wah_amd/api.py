@@ -264,18 +264,24 @@ def decompress_device(d_comp, out_capacity_words):
     return d.result().clone()
 
 
-def gen_uniform_device(n_words, seed, p, device="cuda:0"):
-    """Bernoulli(p) bitmap generated in HBM (bit-exact definition: include/wah_gen.h)."""
+def gen_uniform_device(n_words, seed, p, device="cuda:0", out=None):
+    """Bernoulli(p) bitmap generated in HBM (bit-exact definition: include/wah_gen.h); `out`: write into this tensor."""
     torch = _torch()
-    out = torch.empty(max(int(n_words), 1), dtype=torch.int32, device=device)
+    if out is None:
+        out = torch.empty(max(int(n_words), 1), dtype=torch.int32, device=device)
+    else:
+        _as_words(torch, out)
     _check(lib().wah_gen_uniform_device(out.data_ptr(), int(n_words), int(seed), threshold_for(p),
                                         _stream_ptr(torch)), "wah_gen_uniform_device")
     return out[: int(n_words)]
 
 
-def gen_clustered_device(n_words, seed, mean_run_bits=4096, device="cuda:0"):
+def gen_clustered_device(n_words, seed, mean_run_bits=4096, device="cuda:0", out=None):
     torch = _torch()
-    out = torch.empty(max(int(n_words), 1), dtype=torch.int32, device=device)
+    if out is None:
+        out = torch.empty(max(int(n_words), 1), dtype=torch.int32, device=device)
+    else:
+        _as_words(torch, out)
     _check(lib().wah_gen_clustered_device(out.data_ptr(), int(n_words), int(seed), threshold_for(1.0 / mean_run_bits),
                                           _stream_ptr(torch)), "wah_gen_clustered_device")
     return out[: int(n_words)]

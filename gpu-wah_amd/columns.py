@@ -26,13 +26,50 @@ def column_spec(index, n_words, seed=1337):
     return ColumnSpec(index, KINDS[index % len(KINDS)], seed + index, n_words)
 
 
-def make_column(wah, spec, device):
-    """Generate the column in HBM on `device` (bit-exact definition: include/wah_gen.h)."""
+def make_column(wah, spec, device, out=None):
+    """Generate the column in HBM on `device` (bit-exact definition: include/wah_gen.h); `out`: into this tensor."""
     if spec.kind == "sparse":
-        return wah.gen_uniform_device(spec.n_words, spec.seed, 0.01, device=device)
+        return wah.gen_uniform_device(spec.n_words, spec.seed, 0.01, device=device, out=out)
     if spec.kind == "dense":
-        return wah.gen_uniform_device(spec.n_words, spec.seed, 0.5, device=device)
-    return wah.gen_clustered_device(spec.n_words, spec.seed, 4096, device=device)
+        return wah.gen_uniform_device(spec.n_words, spec.seed, 0.5, device=device, out=out)
+    return wah.gen_clustered_device(spec.n_words, spec.seed, 4096, device=device, out=out)
+
+
+SEGMENT_WORDS = 992  # one reference block: fills never cross it (SURVEY F4)
+
+
+def make_column_matrix(wah, specs, device):
+    """The columns of `specs` (equal lengths, whole 992-word segments) as ONE tensor [len(specs), n_words]."""
+    import torch
+
+    n = specs[0].n_words
+    if any(sp.n_words != n for sp in specs) or n % SEGMENT_WORDS:
+        raise ValueError("a column matrix needs equal column lengths that are multiples of 992 words")
+    m = torch.empty((len(specs), n), dtype=torch.int32, device=device)
+    for row, sp in zip(m, specs):
+        make_column(wah, sp, device, out=row)
+    return m
+
+
+def compress_column_matrix(compressor, matrix, wait=True):
+    """All columns of a contiguous [columns, n_words] matrix in ONE launch (n_words a multiple of 992).
+
+    Fills are maximal inside a 992-word segment and never cross one (F4), and every column is a whole number of
+    segments, so compressing the matrix as one long bitmap yields exactly the columns' streams back to back; the
+    segment index of the `indexed` compressor says where each one starts.  Returns (stream, column_offsets): column c
+    is stream[column_offsets[c] : column_offsets[c + 1]], bit-identical to compressing it alone.  wait=False: only
+    enqueue the launch (read compressor.result() / .seg_offsets after synchronising)."""
+    columns, n = matrix.shape
+    if n % SEGMENT_WORDS or not matrix.is_contiguous():
+        raise ValueError("columns must be contiguous and a multiple of 992 words long")
+    if compressor.seg_offsets is None:
+        raise ValueError("needs DeviceCompressor(..., indexed=True)")
+    compressor.run(matrix.view(-1))
+    if not wait:
+        return None, None
+    stream = compressor.result()
+    segs = n // SEGMENT_WORDS
+    return stream, compressor.seg_offsets[:: segs][: columns + 1]
 
 
 def compress_columns(compressor, columns):

@@ -404,6 +404,32 @@ def test_config5_columns(wah, oracle):
         del dec
 
 
+def test_column_matrix_one_launch(wah, oracle):
+    """Many equal-length columns (whole 992-word segments) in ONE launch: the stream is the columns' streams back to
+    back, each bit-identical to compressing that column alone, and it decodes back to the matrix."""
+    import torch
+
+    n = 992 * 700
+    specs = [wah.columns.column_spec(c, n, seed=50) for c in range(7)]
+    matrix = wah.columns.make_column_matrix(wah, specs, "cuda:0")
+    comp = wah.DeviceCompressor(matrix.numel(), indexed=True)
+    stream, offs = wah.columns.compress_column_matrix(comp, matrix)
+    offs = offs.cpu().numpy()
+    assert offs[0] == 0 and offs[-1] == stream.numel() and len(offs) == len(specs) + 1
+    one = wah.DeviceCompressor(n)
+    for c, sp in enumerate(specs):
+        col = wah.columns.make_column(wah, sp, "cuda:0")
+        assert bool(torch.equal(col, matrix[c]))
+        one.run(col)
+        alone = one.result()
+        assert bool(torch.equal(alone, stream[offs[c]: offs[c + 1]])), c
+        assert np.array_equal(_host(alone), oracle.compress(_host(col))), c
+    back = wah.decompress_device(stream, matrix.numel() + 1)
+    assert bool(torch.equal(back[: matrix.numel()].view(matrix.shape), matrix))
+    with pytest.raises(ValueError):
+        wah.columns.compress_column_matrix(comp, matrix[:, :991].contiguous())
+
+
 # ---------------------------------------------------------------- the reference's own test code
 def test_reference_tests_cpp_against_hip_library(wah):
     """oracle/_ref/ref_tests_hip = /root/reference/tests.cpp compiled in the authoring container and linked
