@@ -33,6 +33,8 @@ from .api import (  # noqa: F401
     decompress_device,
     DeviceCompressor,
     DeviceDecompressor,
+    validate_device,
+    StreamReport,
     gen_uniform_device,
     gen_clustered_device,
     copy_device,

@@ -41,6 +41,7 @@ ABI_SYMBOLS = {
     "wah_decompress_scan_device": (_int, [_vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_expand_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_status": (_int, [_vp, _vp]),
+    "wah_validate_device": (_int, [_vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_gen_uniform_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_gen_clustered_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_copy_device": (_int, [_vp, _vp, _u64, _vp]),
@@ -262,6 +263,25 @@ def decompress_device(d_comp, out_capacity_words):
     d = DeviceDecompressor(d_comp.numel(), out_capacity_words, device=d_comp.device)
     d.run(d_comp)
     return d.result().clone()
+
+
+StreamReport = collections.namedtuple(
+    "StreamReport", "groups words empty_fills fillable_literals crossing_fills unmerged_fills segment_canonical")
+
+
+def validate_device(d_comp):
+    """What a compressed stream contains (include/wah.h: wah_validate_device), without decoding it."""
+    torch = _torch()
+    _as_words(torch, d_comp)
+    c = int(d_comp.numel())
+    ws_bytes = int(lib().wah_decompress_workspace_bytes(c, 0))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=d_comp.device)
+    report = torch.zeros(8, dtype=torch.int64, device=d_comp.device)
+    _check(lib().wah_validate_device(d_comp.data_ptr(), c, report.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(torch)),
+           "wah_validate_device")
+    _check(lib().wah_decompress_status(ws.data_ptr(), _stream_ptr(torch)), "validate")
+    r = report.cpu().tolist()
+    return StreamReport(r[0], r[1], r[2], r[3], r[4], r[5], bool(r[6]))
 
 
 def gen_uniform_device(n_words, seed, p, device="cuda:0", out=None):

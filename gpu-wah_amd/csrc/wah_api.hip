@@ -62,7 +62,7 @@ DecodeLayout decode_layout(uint64_t c_words) {
     l.zero_bytes = round256(l.desc_off + (4 * l.n_tiles + 8) * sizeof(uint32_t));
     l.big_off = l.zero_bytes;
     l.base_off = round256(l.big_off + (l.n_tiles + 1) * sizeof(uint64_t));
-    l.total = round256(l.base_off + (l.n_tiles + 2) * sizeof(uint64_t));
+    l.total = round256(l.base_off + (l.n_tiles + 4) * sizeof(uint64_t)); // + two words for wah_validate_device
     return l;
 }
 
@@ -336,6 +336,31 @@ int wah_decompress_expand_device(const uint32_t *d_comp, uint64_t c_words, uint3
                                  size_t workspace_bytes, void *stream) {
     return decode_common(d_comp, c_words, d_out, out_capacity_words, d_out_info, d_workspace, workspace_bytes, stream,
                          false, true);
+}
+
+int wah_validate_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_report, void *d_workspace,
+                        size_t workspace_bytes, void *stream) {
+    if (!d_report) {
+        g_err[0] = 0;
+        set_err("null pointer");
+        return WAH_ERR_ARG;
+    }
+    // the sums pass gives the tile bases and the totals ([words, groups] land in d_report[0..1] for a moment)
+    const int rc = decode_common(d_comp, c_words, nullptr, 0, d_report, d_workspace, workspace_bytes, stream, true, false);
+    if (rc != WAH_OK) return rc;
+    const DecodeLayout l = decode_layout(c_words);
+    char *ws = static_cast<char *>(d_workspace);
+    // keep the totals aside (behind the tile bases), then build the report
+    uint64_t *info = reinterpret_cast<uint64_t *>(ws + l.base_off) + (l.n_tiles + 1);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(info, d_report, 2 * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess)
+        e = wah::launch_validate(d_comp, c_words, reinterpret_cast<const uint64_t *>(ws + l.base_off), info, d_report, l.n_tiles, s);
+    if (e != hipSuccess) {
+        set_err("validate kernel launch", e);
+        return WAH_ERR_HIP;
+    }
+    return WAH_OK;
 }
 
 int wah_gen_uniform_device(uint32_t *d_out, uint64_t n_words, uint64_t seed, uint64_t threshold, void *stream) {

@@ -1359,6 +1359,67 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
 }
 
 // ===========================================================================
+// stream checker (include/wah.h: wah_validate_device).  One workgroup per 4096-word tile, after the sums pass: the
+// tile bases give every word its group position, so the per-word properties that depend on position (a fill crossing
+// a 1024-group boundary, two mergeable fills inside one segment) can be told from the ones that do not.
+// ===========================================================================
+__global__ __launch_bounds__(kExpandThreads) void validate_kernel(const u32 *comp, u64 c_words, const u64 *tile_base,
+                                                                  const u64 *info, u64 *report) {
+    __shared__ u64 s_wave_sum[kExpandWaves];
+    const u32 lane = lane_id();
+    const u32 wave = wave_id();
+    const u32 tile = blockIdx.x;
+    const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread; // my 16 consecutive words
+    u32 w[kExpandWordsPerThread];
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        w[k] = w0 + k < c_words ? comp[w0 + k] : 0x80000000u; // past the end: nothing
+        mine += word_groups(w[k]);
+    }
+    const u64 incl = wave_scan_incl(mine, lane);
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    u64 p = tile_base[tile] + (incl - mine); // group position of my first word
+    for (u32 k = 0; k < wave; ++k) p += s_wave_sum[k];
+
+    u32 prev = w0 > 0 && w0 - 1 < c_words ? comp[w0 - 1] : 0u; // the word in front of mine (a literal 0 if none)
+    const bool have_prev = w0 > 0;
+    u32 n_empty = 0, n_litfill = 0, n_cross = 0, n_unmerged = 0;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        const u32 x = w[k];
+        if (w0 + k < c_words) {
+            const bool fill = (x & kFillZero) != 0;
+            const u32 cnt = x & kCountMask;
+            n_empty += fill && cnt == 0u;
+            n_litfill += !fill && (x == 0u || x == kOnes31);
+            n_cross += fill && cnt != 0u && (p & (kSegGroups - 1u)) + cnt > kSegGroups;
+            const bool prev_fill = (k > 0 || have_prev) && (prev & kFillZero) && (prev & kCountMask) != 0u;
+            n_unmerged += fill && cnt != 0u && prev_fill && ((prev ^ x) & 0x40000000u) == 0u && (p & (kSegGroups - 1u)) != 0u;
+        }
+        p += word_groups(x);
+        prev = x;
+    }
+    const u32 t_empty = wave_sum32(n_empty), t_lit = wave_sum32(n_litfill), t_cross = wave_sum32(n_cross), t_unm = wave_sum32(n_unmerged);
+    if (lane == 0) {
+        if (t_empty) atomicAdd(reinterpret_cast<unsigned long long *>(report + 2), (unsigned long long)t_empty);
+        if (t_lit) atomicAdd(reinterpret_cast<unsigned long long *>(report + 3), (unsigned long long)t_lit);
+        if (t_cross) atomicAdd(reinterpret_cast<unsigned long long *>(report + 4), (unsigned long long)t_cross);
+        if (t_unm) atomicAdd(reinterpret_cast<unsigned long long *>(report + 5), (unsigned long long)t_unm);
+        if (t_empty | t_lit | t_cross | t_unm) report[6] = 0; // (set to 1 by validate_init_kernel)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        report[0] = info[1];
+        report[1] = info[0];
+    }
+}
+
+__global__ void validate_init_kernel(u64 *report) {
+    if (threadIdx.x < 8) report[threadIdx.x] = threadIdx.x == 6 ? 1ull : 0ull;
+}
+
+// ===========================================================================
 // bench support
 // ===========================================================================
 __global__ void gen_uniform_kernel(u32 *out, u64 n, u64 seed, u64 thr) {
@@ -1490,6 +1551,13 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
     if (parts > 1024) parts = 1024;
     a.parts = (u32)parts;
     hipLaunchKernelGGL(decode_expand_kernel, dim3((unsigned)(n_tiles * parts)), dim3(kExpandThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_validate(const u32 *comp, u64 c_words, const u64 *tile_base, const u64 *info, u64 *report, u64 n_tiles,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(validate_init_kernel, dim3(1), dim3(64), 0, s, report);
+    if (n_tiles) hipLaunchKernelGGL(validate_kernel, dim3((unsigned)n_tiles), dim3(kExpandThreads), 0, s, comp, c_words, tile_base, info, report);
     return hipGetLastError();
 }
 

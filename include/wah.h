@@ -123,6 +123,23 @@ int wah_decompress_expand_device(const uint32_t *d_comp, uint64_t c_words, uint3
 
 int wah_decompress_status(void *d_workspace, void *stream);
 
+/* Stream checker.  The reference decoder accepts ANY sequence of words
+ * (kernels.cu:332-354): fills of count 0, literals that should have been fills, fills that run across the
+ * 1024-group segments the reference's encoder never crosses (kernels.cu:68, tests.cpp:166-172), adjacent fills it
+ * would have merged.  wah_validate_device says what a stream contains, without decoding it.
+ * d_report: 8 x uint64 in device memory:
+ *   [0] groups the stream expands to          [1] decoded words = ceil(31 * groups / 32)
+ *   [2] fill words of count 0                 [3] literal words equal to 0 or 0x7FFFFFFF
+ *   [4] fills crossing a 1024-group boundary  [5] adjacent fills of the same kind inside one segment
+ *   [6] 1 if [2], [3], [4] and [5] are all zero, else 0
+ *   [7] reserved (0)
+ * [6] == 1 exactly when the stream is what compress() of this library / of the reference emits for some bitmap
+ * ("segment-canonical"): every check above clean.  Workspace: wah_decompress_workspace_bytes(c_words, 0).
+ * Asynchronous on `stream`; errors are reported as for wah_decompress_device. */
+#define WAH_REPORT_WORDS 8
+int wah_validate_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_report, void *d_workspace,
+                        size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Benchmark support: synthetic bitmaps generated in HBM (include/wah_gen.h
  * states the bit-exact definition; replaces tests.cpp:42-64), and a plain

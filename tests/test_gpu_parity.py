@@ -252,6 +252,47 @@ def test_compress_fuzz_structured(wah, oracle, seed):
     assert np.array_equal(back[: data.size], data), seed
 
 
+# ---------------------------------------------------------------- stream checker
+def _py_report(st):
+    """Word-by-word restatement of what wah_validate_device counts."""
+    pos = 0
+    empty = lit = cross = unm = 0
+    prev = None
+    for x in (int(v) for v in st):
+        fill, cnt = bool(x & 0x80000000), x & 0x3FFFFFFF
+        if fill and cnt == 0:
+            empty += 1
+        if not fill and x in (0, 0x7FFFFFFF):
+            lit += 1
+        if fill and cnt and (pos % 1024) + cnt > 1024:
+            cross += 1
+        if fill and cnt and prev is not None and (prev & 0x80000000) and (prev & 0x3FFFFFFF) and not ((prev ^ x) & 0x40000000) and pos % 1024:
+            unm += 1
+        pos += cnt if fill else 1
+        prev = x
+    return pos, (31 * pos + 31) // 32, empty, lit, cross, unm, not (empty or lit or cross or unm)
+
+
+def test_validate_streams(wah, oracle):
+    # what compress() emits is segment-canonical, whatever the input
+    for data in (oracle.gen_uniform(992 * 300 + 5, 3, 0.01), oracle.gen_clustered(992 * 500, 4), np.zeros(992 * 40, np.uint32),
+                 np.full(5000, 0xFFFFFFFF, np.uint32), oracle.gen_uniform(4096 * 5, 5, 0.5)):
+        comp = oracle.compress(data)
+        r = wah.validate_device(_dev(comp))
+        assert tuple(r) == _py_report(comp), r
+        assert r.segment_canonical and r.groups == (32 * data.size + 30) // 31
+    # foreign streams: every counter against the word-by-word restatement
+    rng = np.random.default_rng(31)
+    for n_words in (7, 300, 4096 * 3 + 17):
+        st = _random_foreign_stream(rng, n_words, max_groups=10_000_000)
+        r = wah.validate_device(_dev(st))
+        assert tuple(r) == _py_report(st), (n_words, r, _py_report(st))
+    hand = np.array([0x80000000 | 1000, 0x80000000 | 24, 0x80000000 | 5, 0, 0x7FFFFFFF, 0xC0000000, 0xC0000000 | 2000], np.uint32)
+    r = wah.validate_device(_dev(hand))
+    assert (r.empty_fills, r.fillable_literals, r.crossing_fills, r.unmerged_fills) == (1, 2, 1, 1) and not r.segment_canonical
+    assert tuple(wah.validate_device(_dev(np.zeros(0, np.uint32)))) == (0, 0, 0, 0, 0, 0, True)
+
+
 # ---------------------------------------------------------------- API behaviour
 def test_reusable_workspace_and_indexed_output(wah, oracle):
     """Same DeviceCompressor run repeatedly (control block re-zeroed every launch) + the segment index."""
