@@ -301,31 +301,6 @@ __device__ __forceinline__ u32 add_popcount(u32 acc, u64 mask) {
     return acc;
 }
 
-// one step of classify_compact<true> (see there); X0 / X1: operand names of this step's and the next step's groups
-#ifdef WAH_NO_BITOP3
-#define WAH_Z_INSTR(X0) "v_xor_b32 %[nx], %[" X0 "], %[nx]\n\tv_or_b32 %[nx], %[nx], %[tt]\n\t"
-#else
-#define WAH_Z_INSTR(X0) "v_bitop3_b32 %[nx], %[" X0 "], %[nx], %[tt] bitop3:0xbe\n\t"
-#endif
-#define WAH_CLASSIFY_STEP(X0, X1, K)                                          \
-    "v_mov_b32_dpp %[nx], %[" X1 "] wave_rol:1 row_mask:0xf bank_mask:0xf\n\t" \
-    "v_add_u32 %[tt], 1, %[" X0 "]\n\t"                                        \
-    "v_and_b32 %[tt], 0x7ffffffe, %[tt]\n\t"                                   \
-    "v_mov_b32_dpp %[nx], %[" X0 "] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t" \
-    WAH_Z_INSTR(X0)                                                            \
-    "v_cmp_ne_u32 vcc, 0, %[nx]\n\t"                                           \
-    "v_min_u32 %[mt], %[mt], %[tt]\n\t"                                        \
-    "v_add_u32 %[ps], " K ", %[ln]\n\t"                                        \
-    "v_mbcnt_lo_u32_b32 %[nx], vcc_lo, %[cn]\n\t"                              \
-    "v_mbcnt_hi_u32_b32 %[nx], vcc_hi, %[nx]\n\t"                              \
-    "v_bcnt_u32_b32 %[cn], vcc_lo, %[cn]\n\t"                                  \
-    "v_bcnt_u32_b32 %[cn], vcc_hi, %[cn]\n\t"                                  \
-    "v_cndmask_b32 %[nx], %[dm], %[nx], vcc\n\t"                               \
-    "v_lshl_add_u32 %[tt], %[nx], 2, %[vb]\n\t"                                \
-    "v_lshl_add_u32 %[nx], %[nx], 1, %[pb]\n\t"                                \
-    "ds_write_b32 %[tt], %[" X0 "]\n\t"                                        \
-    "ds_write_b16 %[nx], %[ps]\n\t"
-
 template <bool kFull>
 __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigned short *pos, u32 r, u32 lane_v,
                                                 u32 nvalid, bool &any_fill) {
@@ -360,18 +335,33 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
     asm volatile("v_mov_b32 %0, 0x400" : "=v"(dump_slot)); // kStageWords, in a vector register (v_cndmask cannot take a literal)
     static_assert(kStageWords == 0x400, "dump slot literal");
     if (kFull) {
-        // Hand-scheduled, one block for the 16 steps: 15 vector + 2 LDS instructions each, ordered so that no hazard
-        // needs a wait state (a DPP source or a v_cmp mask read as data must be two instructions old; the compiler
-        // pads with s_nop, also around every asm statement, and on this machine a nop costs an issue slot like any
-        // other instruction).
-        u32 nx, tt, ps;
-        asm volatile(WAH_CLASSIFY_STEP("x0", "x1", "0") WAH_CLASSIFY_STEP("x1", "x2", "64") WAH_CLASSIFY_STEP("x2", "x3", "128") WAH_CLASSIFY_STEP("x3", "x4", "192") WAH_CLASSIFY_STEP("x4", "x5", "256") WAH_CLASSIFY_STEP("x5", "x6", "320") WAH_CLASSIFY_STEP("x6", "x7", "384") WAH_CLASSIFY_STEP("x7", "x8", "448") WAH_CLASSIFY_STEP("x8", "x9", "512") WAH_CLASSIFY_STEP("x9", "x10", "576") WAH_CLASSIFY_STEP("x10", "x11", "640") WAH_CLASSIFY_STEP("x11", "x12", "704") WAH_CLASSIFY_STEP("x12", "x13", "768") WAH_CLASSIFY_STEP("x13", "x14", "832") WAH_CLASSIFY_STEP("x14", "x15", "896") WAH_CLASSIFY_STEP("x15", "x16", "960")
-                     : [nx] "=&v"(nx), [tt] "=&v"(tt), [ps] "=&v"(ps), [cn] "+&v"(count_v), [mt] "+&v"(min_t)
+        // Hand-scheduled block for the 16 steps (csrc/classify_block.inc, generated by tools/gen_classify_block.py):
+        // 13.5 vector + 2 LDS instructions per step, software-pipelined by one step so that no hazard needs a wait
+        // state (a DPP source or a v_cmp mask read as data must be two instructions old; the compiler pads with
+        // s_nop, also around every asm statement).  The kernel is bound by vector issue, so
+        // every instruction here is ~0.25 % of its run time.
+        u32 na, ta, nb, tb, ps;
+        const u32 lane2 = lane_v * 0x10001u; // the lane id in both halves: position words are built two at a time
+        asm volatile(
+#include "classify_block.inc"
+                     : [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)
                      : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]), [x12] "v"(x[12]), [x13] "v"(x[13]), [x14] "v"(x[14]), [x15] "v"(x[15]), [x16] "v"(x[16]),
-                       [ln] "v"(lane_v), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)
+                       [ln2] "v"(lane2), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)
                      : "vcc", "memory");
-        any_fill = __ballot(min_t == 0u) != 0;
-        return uniform32(count_v);
+        const u32 count = uniform32(count_v);
+        // Some emitted word is a fill iff some group is one.  Fewer words than groups: certainly.  As many words as
+        // groups (incompressible data): only fills of length 1 are possible, look for an all-zero / all-one group.
+        any_fill = true;
+        if (count == kSegGroups) {
+            u32 lo = x[0], hi = x[0];
+#pragma unroll
+            for (int s = 1; s < (int)kSteps; s += 2) {
+                lo = s + 1 < (int)kSteps ? min(lo, min(x[s], x[s + 1])) : min(lo, x[s]);
+                hi = s + 1 < (int)kSteps ? max(hi, max(x[s], x[s + 1])) : max(hi, x[s]);
+            }
+            any_fill = __ballot(lo == 0u || hi == kOnes31) != 0;
+        }
+        return count;
     }
 #pragma unroll
     for (int s = 0; s < (int)kSteps; ++s) {
