@@ -707,21 +707,49 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
             // then the arithmetic, then 4 writes; every lane rewrites its word (unchanged if a literal).
             const u32 *const src = in_place ? ring : stage;
             const u32 tail = (ring_head + used) & (kStageWords - 1u);
-            for (u32 t = 0; t < count; t += 256u) {
-                u32 v[4], p1[4], p0[4];
+            const u32 padded = (count + 63u) & ~63u; // whole 64-word batches
+            // one word: fill -> type | length, literal -> itself
+            auto final_word = [](u32 v, u32 p1, u32 p0) {
+                const u32 len = (p1 - p0) & 0xFFFFu;
+                return v - 1u >= 0x7FFFFFFEu ? ((v ? kFillOne : kFillZero) | len) : v;
+            };
+            if (tail + padded <= kStageWords && used + padded <= kStageWords) {
+                // usual case: the batches neither wrap around the ring nor reach the oldest pending words, so whole
+                // batches are written (the up to 63 words behind the last real one land on free ring space): no
+                // predicates, no wrap arithmetic, every address is one register + an immediate
+                const u32 *const s0 = src + lane_v;
+                const unsigned short *const q0 = pos + lane_v;
+                u32 *const d0 = ring + tail + lane_v;
+                for (u32 t = 0; t < padded; t += 256u) {
+                    const u32 left = padded - t; // 64, 128, 192 or >= 256
+                    u32 v[4], p1[4], p0[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const u32 j = t + lane_v + 64u * k;
-                    v[k] = src[j];
-                    p1[k] = pos[j + 1u];
-                    p0[k] = pos[j];
+                    for (int k = 0; k < 4; ++k) {
+                        if (64u * k < left) {
+                            v[k] = s0[t + 64u * k];
+                            p1[k] = q0[t + 64u * k + 1u];
+                            p0[k] = q0[t + 64u * k];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (64u * k < left) d0[t + 64u * k] = final_word(v[k], p1[k], p0[k]);
                 }
+            } else {
+                for (u32 t = 0; t < count; t += 256u) {
+                    u32 v[4], p1[4], p0[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const u32 j = t + lane_v + 64u * k;
-                    const u32 len = (p1[k] - p0[k]) & 0xFFFFu;
-                    const u32 w = v[k] - 1u >= 0x7FFFFFFEu ? ((v[k] ? kFillOne : kFillZero) | len) : v[k];
-                    if (j < count) ring[(tail + j) & (kStageWords - 1u)] = w;
+                    for (int k = 0; k < 4; ++k) {
+                        const u32 j = t + lane_v + 64u * k;
+                        v[k] = src[j];
+                        p1[k] = pos[j + 1u];
+                        p0[k] = pos[j];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const u32 j = t + lane_v + 64u * k;
+                        if (j < count) ring[(tail + j) & (kStageWords - 1u)] = final_word(v[k], p1[k], p0[k]);
+                    }
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
