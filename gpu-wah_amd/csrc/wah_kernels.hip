@@ -597,12 +597,24 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
                 const u64 room = a.out_capacity - base;
                 const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + base, (room < cnt ? (u32)room : cnt) * 4u);
                 const u32 off = lane_v * 4u;
-                for (u32 t = 0; t < cnt; t += 256u) { // four LDS reads in flight, then four dense stores
-                    u32 v[4];
+                if (ring_head + ((cnt + 255u) & ~255u) <= kStageWords) {
+                    // no wrap inside the trips (reads behind the last word stay inside the buffer): plain addressing
+                    const u32 *const r0 = ring + ring_head + lane_v;
+                    for (u32 t = 0; t < cnt; t += 256u) { // four LDS reads in flight, then four dense stores
+                        u32 v[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = ring[(ring_head + t + lane_v + 64u * k) & (kStageWords - 1u)];
+                        for (int k = 0; k < 4; ++k) v[k] = r0[t + 64u * k];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(v[k], rsrc, off + 256u * k, t * 4u, 0);
+                        for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(v[k], rsrc, off + 256u * k, t * 4u, 0);
+                    }
+                } else {
+                    for (u32 t = 0; t < cnt; t += 256u) {
+                        u32 v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = ring[(ring_head + t + lane_v + 64u * k) & (kStageWords - 1u)];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(v[k], rsrc, off + 256u * k, t * 4u, 0);
+                    }
                 }
             }
         }
