@@ -292,9 +292,9 @@ __device__ __forceinline__ void stage_slow(const CompressArgs &a, u32 seg, u32 *
 //             (fill lengths are position differences, see the emit loop).
 // kFull = all 1024 groups exist (every segment but possibly the last one of the bitmap).
 // v_bcnt_u32_b32: acc + popcount(mask half).  Spelled out because the compiler would do a uniform popcount on the
-// scalar unit -- and on CDNA4 a SIMD gets one scalar instruction per ~4 cycles (the scalar ALU is shared by the CU's
-// four SIMDs; measured) against one vector instruction per ~2.5.  The inner loop below therefore keeps even its
-// wave-uniform bookkeeping (the running word count) in a vector register and issues no scalar ALU work at all.
+// scalar unit and then needs a scalar add, a v_mov back and hazard nops around them: keeping the wave-uniform running
+// count in a vector register makes the whole step a straight run of vector instructions (the scalar unit is shared
+// by the four SIMDs of a CU and already carries the loop control and hand-off code).
 __device__ __forceinline__ u32 add_popcount(u32 acc, u64 mask) {
     asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "s"((u32)mask));
     asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "s"((u32)(mask >> 32)));
