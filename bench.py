@@ -54,7 +54,7 @@ def parse():
                          "columns: 33554400 = 128 MiB)")
     ap.add_argument("--columns", type=int, default=None, help="columns workload: total number of columns (default 64 per GPU)")
     ap.add_argument("--per-column-launches", action="store_true", help="columns workload: one launch per column instead of one per step")
-    ap.add_argument("--cpu-sample-mib", type=int, default=256, help="size of the CPU-baseline sample")
+    ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="size of the CPU-baseline sample (default: the whole 1 GiB bitmap, about 10 s of host work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1337)
     return ap.parse_args()
