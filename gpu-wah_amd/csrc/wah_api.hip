@@ -191,16 +191,16 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
     const uint64_t grid64 = (uint64_t)resident < l.n_tiles ? (uint64_t)resident : (l.n_tiles ? l.n_tiles : 1);
     const uint64_t generations = (l.n_tiles + grid64 - 1) / grid64;
     const size_t used = round256(l.desc_off + (generations * ((grid64 + 3) & ~3ull) + 8) * sizeof(uint32_t));
-    hipError_t e = hipMemsetAsync(ws, 0, used < l.total ? used : l.total, s);
+    hipError_t e = wah::launch_clear(ws, used < l.total ? used : l.total, s);
     if (e != hipSuccess) {
-        set_err("hipMemsetAsync", e);
+        set_err("clearing the workspace", e);
         return WAH_ERR_HIP;
     }
     if (n_words == 0) {
-        e = hipMemsetAsync(d_out_words, 0, sizeof(uint64_t), s);
-        if (e == hipSuccess && d_segment_offsets) e = hipMemsetAsync(d_segment_offsets, 0, sizeof(uint64_t), s);
+        e = wah::launch_clear(d_out_words, sizeof(uint64_t), s);
+        if (e == hipSuccess && d_segment_offsets) e = wah::launch_clear(d_segment_offsets, sizeof(uint64_t), s);
         if (e != hipSuccess) {
-            set_err("hipMemsetAsync", e);
+            set_err("clearing the workspace", e);
             return WAH_ERR_HIP;
         }
         return WAH_OK;
@@ -274,10 +274,10 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         const uint64_t grid64 = (uint64_t)resident < wg_tiles ? (uint64_t)resident : (wg_tiles ? wg_tiles : 1);
         const uint64_t generations = (wg_tiles + grid64 - 1) / grid64;
         const size_t used = round256(l.desc_off + (generations * ((grid64 + 3) & ~3ull) + 8) * sizeof(uint32_t));
-        e = hipMemsetAsync(ws, 0, used < l.zero_bytes ? used : l.zero_bytes, s);
-        if (e == hipSuccess && c_words == 0) e = hipMemsetAsync(d_out_info, 0, 2 * sizeof(uint64_t), s);
+        e = wah::launch_clear(ws, used < l.zero_bytes ? used : l.zero_bytes, s);
+        if (e == hipSuccess && c_words == 0) e = wah::launch_clear(d_out_info, 2 * sizeof(uint64_t), s);
         if (e != hipSuccess) {
-            set_err("hipMemsetAsync", e);
+            set_err("clearing the workspace", e);
             return WAH_ERR_HIP;
         }
         if (c_words) {

@@ -89,6 +89,7 @@ int compress_grid(int workers, uint32_t *d_ctrl, hipStream_t s);
 hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s);
 int decode_sums_grid(uint32_t *d_ctrl, hipStream_t s);
 hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t n_tiles, hipStream_t s);
+hipError_t launch_clear(void *p, size_t bytes, hipStream_t s);
 hipError_t launch_validate(const uint32_t *comp, uint64_t c_words, const uint64_t *tile_base, const uint64_t *info, uint64_t *report,
                            uint64_t n_tiles, hipStream_t s);
 hipError_t launch_gen_uniform(uint32_t *out, uint64_t n, uint64_t seed, uint64_t thr, hipStream_t s);

@@ -1496,6 +1496,8 @@ int persistent_grid(const void *kernel, int threads, u64 n_tiles) {
 
 // Grid of the persistent compress kernel = how many of its workgroups are resident together, measured once per
 // device by a census launch of the same kernel (the occupancy API is advisory: MI355X_MICROARCH residency notes).
+hipError_t launch_clear(void *p, size_t bytes, hipStream_t s);
+
 template <int W>
 int compress_grid_for(u32 *d_ctrl, hipStream_t s) {
     static int cached[64] = {0};
@@ -1508,7 +1510,7 @@ int compress_grid_for(u32 *d_ctrl, hipStream_t s) {
     a.ctrl = d_ctrl;
     a.census = 1;
     int resident = 0;
-    if (hipMemsetAsync(d_ctrl, 0, kCtlWords * sizeof(u32), s) == hipSuccess) {
+    if (launch_clear(d_ctrl, kCtlWords * sizeof(u32), s) == hipSuccess) {
         hipLaunchKernelGGL(compress_kernel<W>, dim3(upper), dim3((W + 1) * 64), 0, s, a);
         u32 seen = 0;
         if (hipGetLastError() == hipSuccess &&
@@ -1546,7 +1548,7 @@ int decode_sums_grid(u32 *d_ctrl, hipStream_t s) {
     a.ctrl = d_ctrl;
     a.census = 1;
     int resident = 0;
-    if (hipMemsetAsync(d_ctrl, 0, kCtlWords * sizeof(u32), s) == hipSuccess) {
+    if (launch_clear(d_ctrl, kCtlWords * sizeof(u32), s) == hipSuccess) {
         hipLaunchKernelGGL(decode_sums_kernel, dim3(upper), dim3((kSumWorkers + 1) * 64), 0, s, a);
         u32 seen = 0;
         if (hipGetLastError() == hipSuccess &&
@@ -1588,6 +1590,20 @@ hipError_t launch_validate(const u32 *comp, u64 c_words, const u64 *tile_base, c
                            hipStream_t s) {
     hipLaunchKernelGGL(validate_init_kernel, dim3(1), dim3(64), 0, s, report);
     if (n_tiles) hipLaunchKernelGGL(validate_kernel, dim3((unsigned)n_tiles), dim3(kExpandThreads), 0, s, comp, c_words, tile_base, info, report);
+    return hipGetLastError();
+}
+
+// Zero `bytes` bytes (a multiple of 4) at p (4-byte aligned).  A kernel of our own rather than hipMemsetAsync: the
+// device-pointer API is meant to be captured into HIP graphs, and a captured memset node did not reliably write
+// zeros when the graph was replayed (ROCm 7.2, observed on MI355X: tests/test_gpu_parity.py graph test).
+__global__ void clear_kernel(u32 *p, u64 n_words) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (u64)gridDim.x * blockDim.x) p[i] = 0u;
+}
+hipError_t launch_clear(void *p, size_t bytes, hipStream_t s) {
+    const u64 n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    const u64 blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(clear_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, static_cast<u32 *>(p), n);
     return hipGetLastError();
 }
 

@@ -314,6 +314,39 @@ def test_reusable_workspace_and_indexed_output(wah, oracle):
     torch.cuda.synchronize()
 
 
+def test_device_api_is_graph_capturable(wah, oracle):
+    """Nothing is allocated and nothing synchronises inside the device-pointer calls (after the first call on a device,
+    which runs the residency census): a compress + decompress pair can be captured into a HIP graph and replayed."""
+    import torch
+
+    n = 992 * 3000 + 5
+    a = _dev(oracle.gen_uniform(n, 1, 0.01))
+    b = _dev(oracle.gen_clustered(n, 2))
+    d_in = a.clone()
+    comp = wah.DeviceCompressor(n)
+    dec = wah.DeviceDecompressor(comp.capacity, n + 1)
+    comp.run(d_in)  # first call: census, outside the capture
+    dec.run(comp.out, comp.capacity)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            comp.run(d_in)
+            # the compressed length is only known on the device: decode a stream padded with empty fills to capacity
+            dec.run(comp.out, comp.capacity)
+    for src in (a, b, a):
+        comp.out.fill_(-2147483648)  # 0x80000000: a fill of count 0, expands to nothing
+        d_in.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        comp.status()
+        dec.status()
+        c = int(comp.count.item())
+        assert np.array_equal(_host(comp.out[:c]), oracle.compress(_host(src)))
+        assert bool(torch.equal(dec.out[:n], src))
+
+
 def test_misaligned_input_pointer(wah, oracle):
     """A device pointer that is only 4-byte aligned takes the scalar staging path: same words."""
     n = 992 * 50 + 3
