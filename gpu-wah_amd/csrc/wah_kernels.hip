@@ -303,7 +303,7 @@ __device__ __forceinline__ u32 add_popcount(u32 acc, u64 mask) {
 
 template <bool kFull>
 __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigned short *pos, u32 r, u32 lane_v,
-                                                u32 nvalid, bool &any_fill) {
+                                                u32 nvalid, bool long_fills, bool &any_fill) {
     // phase 1: all 16 LDS reads, then the funnel shifts: every staged word is in registers before the first
     // compacted word overwrites the staging buffer
     u32 x[kSteps + 1];
@@ -342,12 +342,23 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
         // every instruction here is ~0.25 % of its run time.
         u32 na, ta, nb, tb, ps;
         const u32 lane2 = lane_v * 0x10001u; // the lane id in both halves: position words are built two at a time
-        asm volatile(
+        // two schedules of the same block: `long_fills` (the wave's previous segment compressed to a few words) takes
+        // the one in which a step without any run end branches over the ranking and the stores
+#define WAH_CLASSIFY_OPERANDS                                                                                                  \
+    : [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)                      \
+    : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]), [x12] "v"(x[12]), [x13] "v"(x[13]), [x14] "v"(x[14]), [x15] "v"(x[15]), [x16] "v"(x[16]),                                                                                                                  \
+      [ln2] "v"(lane2), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)                                                  \
+    : "vcc", "memory"
+        if (long_fills) {
+            asm volatile(
+#include "classify_block_skip.inc"
+                WAH_CLASSIFY_OPERANDS);
+        } else {
+            asm volatile(
 #include "classify_block.inc"
-                     : [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)
-                     : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]), [x12] "v"(x[12]), [x13] "v"(x[13]), [x14] "v"(x[14]), [x15] "v"(x[15]), [x16] "v"(x[16]),
-                       [ln2] "v"(lane2), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)
-                     : "vcc", "memory");
+                WAH_CLASSIFY_OPERANDS);
+        }
+#undef WAH_CLASSIFY_OPERANDS
         const u32 count = uniform32(count_v);
         // Some emitted word is a fill iff some group is one.  Fewer words than groups: certainly.  As many words as
         // groups (incompressible data): only fills of length 1 are possible, look for an all-zero / all-one group.
@@ -631,6 +642,9 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
         return true;
     };
 
+    // the last segment compressed to a handful of words: the next one probably consists of long fills too
+    constexpr u32 kLongFillsBelow = 256;
+    bool long_fills = false;
     u32 gen = 0;
     for (u32 tile = arrival; tile < a.n_tiles && ok; tile += stride, ++gen) {
         const u32 seg = tile * W + wave;
@@ -667,8 +681,9 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
             const u32 nvalid = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
             if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
             const u32 *sp = stage + ((31u * lane_v) >> 5);
-            count = nvalid == kSegGroups ? classify_compact<true>(sp, stage, pos, r, lane_v, nvalid, any_fill)
-                                         : classify_compact<false>(sp, stage, pos, r, lane_v, nvalid, any_fill);
+            count = nvalid == kSegGroups ? classify_compact<true>(sp, stage, pos, r, lane_v, nvalid, long_fills, any_fill)
+                                         : classify_compact<false>(sp, stage, pos, r, lane_v, nvalid, long_fills, any_fill);
+            long_fills = count < kLongFillsBelow;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         WAH_STAMP(1);
