@@ -644,7 +644,7 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
 
     // the last segment compressed to a handful of words: the next one probably consists of long fills too
     constexpr u32 kLongFillsBelow = 256;
-    bool long_fills = false;
+    bool long_fills = false, whole_run = false;
     u32 gen = 0;
     for (u32 tile = arrival; tile < a.n_tiles && ok; tile += stride, ++gen) {
         const u32 seg = tile * W + wave;
@@ -658,7 +658,20 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
         if (threadIdx.x == 0 && a.seg_offsets) a.seg_offsets[(u64)tile * 4 + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
         const bool has_seg = seg < a.n_segments;
-        if (has_seg) {
+        // Inside a very long run (the wave's last segment was one or two words) the whole segment is probably one
+        // fill: decide that from the prefetched registers -- all 992 words zero, or all ones -- and skip staging and
+        // classification.  (Lanes 56..63 of the fourth load lie behind the segment and read as zero.)
+        u32 uniform_kind = 0; // 1: all zero, 2: all ones
+        if (has_seg && pre_valid && whole_run && seg + 1u < a.n_segments) {
+            const u32x4 o = pre.v[0] | pre.v[1] | pre.v[2] | pre.v[3];
+            const u32x4 tail_fix = lane >= 56u ? u32x4{~0u, ~0u, ~0u, ~0u} : u32x4{0, 0, 0, 0};
+            const u32x4 n = pre.v[0] & pre.v[1] & pre.v[2] & (pre.v[3] | tail_fix);
+            if (__ballot((o.x | o.y | o.z | o.w) != 0u) == 0)
+                uniform_kind = 1;
+            else if (__ballot((n.x & n.y & n.z & n.w) != ~0u) == 0)
+                uniform_kind = 2;
+        }
+        if (has_seg && !uniform_kind) {
             if (pre_valid)
                 stage_prefetched(pre, stage, lane);
             else
@@ -677,13 +690,24 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
         }
 
         bool any_fill = false;
-        if (has_seg) {
+        if (uniform_kind) {
+            // one run end, at the last group: what classify_compact would have left in the stage buffer
+            if (lane == 0) {
+                stage[0] = uniform_kind == 1 ? 0u : kOnes31;
+                pos[0] = 0xFFFFu;
+                pos[1] = (unsigned short)(kSegGroups - 1u);
+            }
+            count = 1;
+            any_fill = true;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else if (has_seg) {
             const u32 nvalid = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
             if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
             const u32 *sp = stage + ((31u * lane_v) >> 5);
             count = nvalid == kSegGroups ? classify_compact<true>(sp, stage, pos, r, lane_v, nvalid, long_fills, any_fill)
                                          : classify_compact<false>(sp, stage, pos, r, lane_v, nvalid, long_fills, any_fill);
             long_fills = count < kLongFillsBelow;
+            whole_run = count <= 2u;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         WAH_STAMP(1);
