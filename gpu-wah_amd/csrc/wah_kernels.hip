@@ -611,16 +611,12 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
                 if (ring_head + ((cnt + 255u) & ~255u) <= kStageWords) {
                     // no wrap inside the trips (reads behind the last word stay inside the buffer): plain addressing
                     const u32 *const r0 = ring + ring_head + lane_v;
-                    const u32 padded = (cnt + 63u) & ~63u; // whole 64-word batches; a short tile is one read and one store
-                    for (u32 t = 0; t < padded; t += 256u) { // up to four LDS reads in flight, then as many dense stores
-                        const u32 left = padded - t;
+                    for (u32 t = 0; t < cnt; t += 256u) { // four LDS reads in flight, then four dense stores
                         u32 v[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (64u * k < left) v[k] = r0[t + 64u * k];
+                        for (int k = 0; k < 4; ++k) v[k] = r0[t + 64u * k];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (64u * k < left) __builtin_amdgcn_raw_buffer_store_b32(v[k], rsrc, off + 256u * k, t * 4u, 0);
+                        for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(v[k], rsrc, off + 256u * k, t * 4u, 0);
                     }
                 } else {
                     for (u32 t = 0; t < cnt; t += 256u) {
