@@ -34,6 +34,7 @@ from .api import (  # noqa: F401
     DeviceCompressor,
     DeviceDecompressor,
     validate_device,
+    bitop_device,
     StreamReport,
     gen_uniform_device,
     gen_clustered_device,

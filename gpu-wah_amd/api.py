@@ -42,6 +42,9 @@ ABI_SYMBOLS = {
     "wah_decompress_expand_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_status": (_int, [_vp, _vp]),
     "wah_validate_device": (_int, [_vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_bitop_scratch_bytes": (_sz, [_u64, _u64, _u64]),
+    "wah_bitop_device": (_int, [_int, _u64, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_bitop_status": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_gen_uniform_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_gen_clustered_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_copy_device": (_int, [_vp, _vp, _u64, _vp]),
@@ -263,6 +266,27 @@ def decompress_device(d_comp, out_capacity_words):
     d = DeviceDecompressor(d_comp.numel(), out_capacity_words, device=d_comp.device)
     d.run(d_comp)
     return d.result().clone()
+
+
+OPS = {"and": 0, "or": 1, "xor": 2, "andnot": 3}
+
+
+def bitop_device(op, d_a, d_b, n_words):
+    """compress(A op B) from the two compressed bitmaps of n_words words each (include/wah.h: wah_bitop_device)."""
+    torch = _torch()
+    _as_words(torch, d_a)
+    _as_words(torch, d_b)
+    n, ca, cb = int(n_words), int(d_a.numel()), int(d_b.numel())
+    cap = max_compressed_words(n)
+    sc_bytes = int(lib().wah_bitop_scratch_bytes(n, ca, cb))
+    scratch = torch.empty(sc_bytes, dtype=torch.uint8, device=d_a.device)
+    out = torch.empty(max(cap, 1), dtype=torch.int32, device=d_a.device)
+    count = torch.zeros(1, dtype=torch.int64, device=d_a.device)
+    sp = _stream_ptr(torch)
+    _check(lib().wah_bitop_device(OPS[op], n, d_a.data_ptr(), ca, d_b.data_ptr(), cb, out.data_ptr(), cap, count.data_ptr(),
+                                  scratch.data_ptr(), sc_bytes, sp), "wah_bitop_device")
+    _check(lib().wah_bitop_status(scratch.data_ptr(), n, ca, cb, sp), "bitop")
+    return out[: int(count.item())].clone()
 
 
 StreamReport = collections.namedtuple(

@@ -162,9 +162,9 @@ size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_wo
     return decode_layout(c_words).total;
 }
 
-int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
-                                uint64_t *d_out_words, uint64_t *d_segment_offsets, void *d_workspace,
-                                size_t workspace_bytes, void *stream) {
+static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int op, const wah::PairCheck *check, uint64_t n_words,
+                                uint32_t *d_out, uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_segment_offsets,
+                                void *d_workspace, size_t workspace_bytes, void *stream) {
     g_err[0] = 0;
     if (!d_out_words || !d_workspace || (n_words && (!d_in || !d_out))) {
         set_err("null pointer");
@@ -221,13 +221,31 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
     a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
     a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
     a.census = 0;
+    a.in2 = d_in2;
+    a.op = (uint32_t)op;
     const int grid = (int)grid64;
-    e = wah::launch_compress(workers, a, grid, s);
+    if (d_in2) {
+        if (!a.fast_segments || !aligned16(d_in2) || workers != 15) {
+            set_err("pair mode needs 16-byte aligned bitmaps");
+            return WAH_ERR_ARG;
+        }
+        if (check) e = wah::launch_bitop_check(check->info_a, check->info_b, check->ctrl_a, check->ctrl_b, check->groups, a.ctrl, s);
+        if (e == hipSuccess) e = wah::launch_compress_pair(a, grid, s);
+    } else {
+        e = wah::launch_compress(workers, a, grid, s);
+    }
     if (e != hipSuccess) {
         set_err("compress kernel launch", e);
         return WAH_ERR_HIP;
     }
     return WAH_OK;
+}
+
+int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
+                                uint64_t *d_out_words, uint64_t *d_segment_offsets, void *d_workspace,
+                                size_t workspace_bytes, void *stream) {
+    return compress_device_impl(d_in, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, d_segment_offsets,
+                                d_workspace, workspace_bytes, stream);
 }
 
 int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
@@ -361,6 +379,70 @@ int wah_validate_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_re
         return WAH_ERR_HIP;
     }
     return WAH_OK;
+}
+
+// ---- bitwise operations on two compressed bitmaps -------------------------------------------------------------
+namespace {
+struct BitopLayout {
+    size_t bitmap_a, bitmap_b, info_a, info_b, ws_a, ws_b, ws_c, total;
+    size_t ws_a_bytes, ws_b_bytes, ws_c_bytes;
+    uint64_t decoded_capacity;
+};
+BitopLayout bitop_layout(uint64_t n_words, uint64_t a_words, uint64_t b_words) {
+    BitopLayout l;
+    l.decoded_capacity = n_words + 1; // ceil(31 G / 32) is n_words or n_words + 1
+    const size_t bm = round256(l.decoded_capacity * sizeof(uint32_t));
+    l.ws_a_bytes = wah_decompress_workspace_bytes(a_words, l.decoded_capacity);
+    l.ws_b_bytes = wah_decompress_workspace_bytes(b_words, l.decoded_capacity);
+    l.ws_c_bytes = wah_compress_workspace_bytes(n_words);
+    l.bitmap_a = 0;
+    l.bitmap_b = bm;
+    l.info_a = 2 * bm;
+    l.info_b = l.info_a + 256;
+    l.ws_a = l.info_b + 256;
+    l.ws_b = l.ws_a + round256(l.ws_a_bytes);
+    l.ws_c = l.ws_b + round256(l.ws_b_bytes);
+    l.total = l.ws_c + round256(l.ws_c_bytes);
+    return l;
+}
+} // namespace
+
+size_t wah_bitop_scratch_bytes(uint64_t n_words, uint64_t a_words, uint64_t b_words) {
+    return bitop_layout(n_words, a_words, b_words).total;
+}
+
+int wah_bitop_device(int op, uint64_t n_words, const uint32_t *d_a, uint64_t a_words, const uint32_t *d_b,
+                     uint64_t b_words, uint32_t *d_out, uint64_t out_capacity_words, uint64_t *d_out_words,
+                     void *d_scratch, size_t scratch_bytes, void *stream) {
+    g_err[0] = 0;
+    if (op < WAH_OP_AND || op > WAH_OP_ANDNOT || !d_scratch || (reinterpret_cast<uintptr_t>(d_scratch) & 255u)) {
+        set_err("bad operation or scratch pointer");
+        return WAH_ERR_ARG;
+    }
+    const BitopLayout l = bitop_layout(n_words, a_words, b_words);
+    if (scratch_bytes < l.total) {
+        set_err("scratch too small");
+        return WAH_ERR_WORKSPACE;
+    }
+    char *sc = static_cast<char *>(d_scratch);
+    uint32_t *bm_a = reinterpret_cast<uint32_t *>(sc + l.bitmap_a), *bm_b = reinterpret_cast<uint32_t *>(sc + l.bitmap_b);
+    uint64_t *info_a = reinterpret_cast<uint64_t *>(sc + l.info_a), *info_b = reinterpret_cast<uint64_t *>(sc + l.info_b);
+    int rc = wah_decompress_device(d_a, a_words, bm_a, l.decoded_capacity, info_a, sc + l.ws_a, l.ws_a_bytes, stream);
+    if (rc == WAH_OK) rc = wah_decompress_device(d_b, b_words, bm_b, l.decoded_capacity, info_b, sc + l.ws_b, l.ws_b_bytes, stream);
+    if (rc != WAH_OK) return rc;
+    wah::PairCheck check;
+    check.info_a = info_a;
+    check.info_b = info_b;
+    check.ctrl_a = reinterpret_cast<const uint32_t *>(sc + l.ws_a);
+    check.ctrl_b = reinterpret_cast<const uint32_t *>(sc + l.ws_b);
+    check.groups = wah_max_compressed_words(n_words);
+    return compress_device_impl(bm_a, bm_b, op, &check, n_words, d_out, out_capacity_words, d_out_words, nullptr, sc + l.ws_c,
+                                l.ws_c_bytes, stream);
+}
+
+int wah_bitop_status(void *d_scratch, uint64_t n_words, uint64_t a_words, uint64_t b_words, void *stream) {
+    if (!d_scratch) return WAH_ERR_ARG;
+    return read_status(static_cast<char *>(d_scratch) + bitop_layout(n_words, a_words, b_words).ws_c, stream);
 }
 
 int wah_gen_uniform_device(uint32_t *d_out, uint64_t n_words, uint64_t seed, uint64_t threshold, void *stream) {

@@ -42,6 +42,8 @@ constexpr int kExpandWaves = 4;      // wavefronts of an expand workgroup (each 
 
 struct CompressArgs {
     const uint32_t *in;
+    const uint32_t *in2;   // pair mode (wah_bitop_device): second bitmap of the same length, combined word by word
+    uint32_t op;           // ... with WAH_OP_AND / OR / XOR / ANDNOT
     uint64_t n_words;
     uint32_t n_segments;          // ceil(G / 1024)
     uint32_t n_tiles;             // ceil(n_segments / kCompressWaves)
@@ -83,8 +85,18 @@ struct ExpandArgs {
     uint32_t parts; // workgroups that share one tile's output segments (set by the launcher)
 };
 
+// wah_bitop_device: what the operands' decodes left behind, checked on the device before the combining pass
+struct PairCheck {
+    const uint64_t *info_a, *info_b; // [decoded words, groups] of the two operands
+    const uint32_t *ctrl_a, *ctrl_b; // their decode control blocks (error bits)
+    uint64_t groups;                 // what both must have expanded to
+};
+
 // launchers (wah_kernels.hip)
 hipError_t launch_compress(int workers, const CompressArgs &a, int grid, hipStream_t s);
+hipError_t launch_compress_pair(const CompressArgs &a, int grid, hipStream_t s);
+hipError_t launch_bitop_check(const uint64_t *info_a, const uint64_t *info_b, const uint32_t *ctrl_a, const uint32_t *ctrl_b, uint64_t groups,
+                              uint32_t *ctrl, hipStream_t s);
 int compress_grid(int workers, uint32_t *d_ctrl, hipStream_t s);
 hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s);
 int decode_sums_grid(uint32_t *d_ctrl, hipStream_t s);

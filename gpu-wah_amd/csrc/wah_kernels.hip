@@ -259,6 +259,29 @@ __device__ __forceinline__ void prefetch_segment(const CompressArgs &a, u32 seg,
     p.v[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 3072u, 0, 0);
 }
 
+// pair mode: the same four loads from the second bitmap
+__device__ __forceinline__ void prefetch_segment2(const CompressArgs &a, u32 seg, u32 lane, Prefetch &p) {
+    const u32 bytes = seg < a.full_segments ? kSegWords * 4u : a.tail_bytes;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.in2 + (u64)seg * kSegWords, bytes);
+    const u32 off = lane * 16u;
+    p.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    p.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 1024u, 0, 0);
+    p.v[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 2048u, 0, 0);
+    p.v[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 3072u, 0, 0);
+}
+// ... and the word-by-word combination (include/wah.h: WAH_OP_*); words behind the bitmap stay zero for every op
+__device__ __forceinline__ void combine_pair(Prefetch &p, const Prefetch &q, u32 op) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        switch (op) {
+        case 0: p.v[k] = p.v[k] & q.v[k]; break;
+        case 1: p.v[k] = p.v[k] | q.v[k]; break;
+        case 2: p.v[k] = p.v[k] ^ q.v[k]; break;
+        default: p.v[k] = p.v[k] & ~q.v[k]; break;
+        }
+    }
+}
+
 // the fourth store also zeroes word 992, the look-ahead word of the last group (and the unused words up to 1023)
 __device__ __forceinline__ void stage_prefetched(const Prefetch &p, u32 *lds, u32 lane) {
     u32x4 *dst = reinterpret_cast<u32x4 *>(lds);
@@ -461,7 +484,7 @@ __device__ __forceinline__ bool lds_wait_reached(const u32 *counter, u32 value, 
 constexpr u32 kDepth = 8;      // generations a workgroup keeps bookkeeping for (power of two)
 constexpr u32 kMaxPending = 4; // finished tiles a worker may hold in LDS while their offsets resolve (< kDepth - 2)
 
-template <int W>
+template <int W, bool kPair = false>
 __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_out[2][W][kOutWords];
     __shared__ unsigned short s_pos[W][kPosEntries];
@@ -563,14 +586,16 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
     const u32 r = (31u * lane) & 31u;
     unsigned short *const pos = s_pos[wave];
 
-    Prefetch pre;
+    Prefetch pre, pre2; // pre2: pair mode only (wah_bitop_device), the second bitmap's words
     pre.v[0] = pre.v[1] = pre.v[2] = pre.v[3] = u32x4{0, 0, 0, 0};
+    pre2 = pre;
     // wave-uniform: `pre` holds the current tile's segment (always, unless the input is only 4-byte aligned)
     bool pre_valid = false;
     {
         const u32 seg = arrival * W + wave;
         if (arrival < a.n_tiles && seg < a.n_segments && a.fast_segments) {
             prefetch_segment(a, seg, lane, pre);
+            if (kPair) prefetch_segment2(a, seg, lane, pre2);
             pre_valid = true;
         }
     }
@@ -658,6 +683,7 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
         if (threadIdx.x == 0 && a.seg_offsets) a.seg_offsets[(u64)tile * 4 + 0] = __builtin_amdgcn_s_memrealtime();
 #endif
         const bool has_seg = seg < a.n_segments;
+        if (kPair && pre_valid) combine_pair(pre, pre2, a.op); // from here on `pre` is the combined bitmap
         // Inside a very long run (the wave's last segment was one or two words) the whole segment is probably one
         // fill: decide that from the prefetched registers -- all 992 words zero, or all ones -- and skip staging and
         // classification.  (Lanes 56..63 of the fourth load lie behind the segment and read as zero.)
@@ -686,7 +712,10 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
             const u32 next_tile = tile + stride;
             const u32 nseg = next_tile * W + wave;
             pre_valid = next_tile < a.n_tiles && nseg < a.n_segments && a.fast_segments;
-            if (pre_valid) prefetch_segment(a, nseg, lane, pre);
+            if (pre_valid) {
+                prefetch_segment(a, nseg, lane, pre);
+                if (kPair) prefetch_segment2(a, nseg, lane, pre2);
+            }
         }
 
         bool any_fill = false;
@@ -1573,6 +1602,26 @@ hipError_t launch_compress(int workers, const CompressArgs &a, int grid, hipStre
         hipLaunchKernelGGL(compress_kernel<15>, dim3(grid), dim3(16 * 64), 0, s, a);
     else
         hipLaunchKernelGGL(compress_kernel<7>, dim3(grid), dim3(8 * 64), 0, s, a);
+    return hipGetLastError();
+}
+
+// wah_bitop_device: both operands must have expanded to the bitmap length the caller named, without errors of their own
+__global__ void bitop_check_kernel(const u64 *info_a, const u64 *info_b, const u32 *ctrl_a, const u32 *ctrl_b, u64 groups, u32 *ctrl) {
+    if (threadIdx.x == 0) {
+        u32 err = ctrl_a[kCtlError] | ctrl_b[kCtlError];
+        if (info_a[1] != groups || info_b[1] != groups) err |= kErrStream;
+        if (err) atomicOr(ctrl + kCtlError, err);
+    }
+}
+hipError_t launch_bitop_check(const u64 *info_a, const u64 *info_b, const u32 *ctrl_a, const u32 *ctrl_b, u64 groups, u32 *ctrl,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(bitop_check_kernel, dim3(1), dim3(64), 0, s, info_a, info_b, ctrl_a, ctrl_b, groups, ctrl);
+    return hipGetLastError();
+}
+
+// pair mode (wah_bitop_device): same kernel, two inputs combined while they are staged; needs the fast path
+hipError_t launch_compress_pair(const CompressArgs &a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((compress_kernel<15, true>), dim3(grid), dim3(16 * 64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -141,6 +141,26 @@ int wah_validate_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_re
                         size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Bitwise operations on two compressed bitmaps (not in the reference, whose README.md:10
+ * names them as the reason bitmap indexes use WAH).  Both streams must describe bitmaps of n_words words.  The
+ * result is what compress() gives for (A op B): decode A, decode B (decode_sums + decode_expand each) into scratch,
+ * then ONE pass of the compress kernel that combines the two bitmaps while it stages them -- three streaming passes
+ * at HBM speed, nothing leaves the device.
+ *   d_scratch: wah_bitop_scratch_bytes(n_words, a_words, b_words) bytes, 256-byte aligned.
+ *   Errors that only the device sees (a stream that does not expand to n_words words, output capacity) are read
+ *   back by wah_bitop_status(), which synchronises the stream.
+ * ------------------------------------------------------------------------- */
+#define WAH_OP_AND 0
+#define WAH_OP_OR 1
+#define WAH_OP_XOR 2
+#define WAH_OP_ANDNOT 3 /* A & ~B */
+size_t wah_bitop_scratch_bytes(uint64_t n_words, uint64_t a_words, uint64_t b_words);
+int wah_bitop_device(int op, uint64_t n_words, const uint32_t *d_a, uint64_t a_words, const uint32_t *d_b,
+                     uint64_t b_words, uint32_t *d_out, uint64_t out_capacity_words, uint64_t *d_out_words,
+                     void *d_scratch, size_t scratch_bytes, void *stream);
+int wah_bitop_status(void *d_scratch, uint64_t n_words, uint64_t a_words, uint64_t b_words, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Benchmark support: synthetic bitmaps generated in HBM (include/wah_gen.h
  * states the bit-exact definition; replaces tests.cpp:42-64), and a plain
  * 16-byte-per-lane copy used as the on-box HBM ceiling.

@@ -293,6 +293,24 @@ def test_validate_streams(wah, oracle):
     assert tuple(wah.validate_device(_dev(np.zeros(0, np.uint32)))) == (0, 0, 0, 0, 0, 0, True)
 
 
+# ---------------------------------------------------------------- bitwise operations on compressed bitmaps
+def test_bitops_on_compressed_bitmaps(wah, oracle):
+    """wah_bitop_device(op, A, B) == compress(decompress(A) op decompress(B)), for whole-segment and ragged lengths."""
+    ops = {"and": np.bitwise_and, "or": np.bitwise_or, "xor": np.bitwise_xor, "andnot": lambda x, y: x & ~y}
+    for n in (992 * 64, 992 * 300 + 17, 5):
+        a = oracle.gen_uniform(n, 11, 0.05)
+        b = oracle.gen_clustered(n, 12, 700)
+        ca, cb = oracle.compress(a), oracle.compress(b)
+        for name, fn in ops.items():
+            want = oracle.compress(fn(a, b).astype(np.uint32))
+            got = _host(wah.bitop_device(name, _dev(ca), _dev(cb), n))
+            assert got.shape == want.shape and np.array_equal(got, want), (n, name)
+    # operands that do not describe bitmaps of the stated length are refused
+    a = oracle.gen_uniform(992 * 10, 1, 0.1)
+    with pytest.raises(wah.WahError):
+        wah.bitop_device("and", _dev(oracle.compress(a)), _dev(oracle.compress(a[:992 * 9])), a.size)
+
+
 # ---------------------------------------------------------------- API behaviour
 def test_reusable_workspace_and_indexed_output(wah, oracle):
     """Same DeviceCompressor run repeatedly (control block re-zeroed every launch) + the segment index."""
