@@ -35,6 +35,7 @@ from .api import (  # noqa: F401
     DeviceDecompressor,
     validate_device,
     bitop_device,
+    merge_fills_device,
     StreamReport,
     gen_uniform_device,
     gen_clustered_device,

@@ -42,6 +42,8 @@ ABI_SYMBOLS = {
     "wah_decompress_expand_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_status": (_int, [_vp, _vp]),
     "wah_validate_device": (_int, [_vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_merge_fills_workspace_bytes": (_sz, [_u64]),
+    "wah_merge_fills_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_bitop_scratch_bytes": (_sz, [_u64, _u64, _u64]),
     "wah_bitop_device": (_int, [_int, _u64, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_bitop_status": (_int, [_vp, _u64, _u64, _u64, _vp]),
@@ -266,6 +268,22 @@ def decompress_device(d_comp, out_capacity_words):
     d = DeviceDecompressor(d_comp.numel(), out_capacity_words, device=d_comp.device)
     d.run(d_comp)
     return d.result().clone()
+
+
+def merge_fills_device(d_comp):
+    """The stream with adjacent fills of one kind merged and empty fills dropped: unsegmented WAH (wah_merge_fills_device)."""
+    torch = _torch()
+    _as_words(torch, d_comp)
+    c = int(d_comp.numel())
+    ws_bytes = int(lib().wah_merge_fills_workspace_bytes(c))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=d_comp.device)
+    out = torch.empty(max(c, 1), dtype=torch.int32, device=d_comp.device)
+    count = torch.zeros(1, dtype=torch.int64, device=d_comp.device)
+    sp = _stream_ptr(torch)
+    _check(lib().wah_merge_fills_device(d_comp.data_ptr(), c, out.data_ptr(), c, count.data_ptr(), ws.data_ptr(), ws_bytes, sp),
+           "wah_merge_fills_device")
+    _check(lib().wah_decompress_status(ws.data_ptr(), sp), "merge_fills")
+    return out[: int(count.item())].clone()
 
 
 OPS = {"and": 0, "or": 1, "xor": 2, "andnot": 3}

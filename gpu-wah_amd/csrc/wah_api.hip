@@ -381,6 +381,63 @@ int wah_validate_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_re
     return WAH_OK;
 }
 
+// ---- merged (unsegmented) form -------------------------------------------------------------------------------
+namespace {
+struct MergeLayout {
+    size_t decode_bytes, kept_off, pos_off, info_off, total;
+};
+MergeLayout merge_layout(uint64_t c_words) {
+    MergeLayout l;
+    const DecodeLayout d = decode_layout(c_words);
+    l.decode_bytes = round256(d.total);
+    l.kept_off = l.decode_bytes;
+    l.info_off = round256(l.kept_off + (d.n_tiles + 2) * sizeof(uint64_t));
+    l.pos_off = l.info_off + 256;
+    l.total = round256(l.pos_off + (c_words + 1) * sizeof(uint64_t));
+    return l;
+}
+} // namespace
+
+size_t wah_merge_fills_workspace_bytes(uint64_t c_words) { return merge_layout(c_words).total; }
+
+int wah_merge_fills_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
+                           uint64_t *d_out_words, void *d_workspace, size_t workspace_bytes, void *stream) {
+    g_err[0] = 0;
+    if (!d_out_words || !d_workspace || (c_words && (!d_comp || !d_out))) {
+        set_err("null pointer");
+        return WAH_ERR_ARG;
+    }
+    const MergeLayout l = merge_layout(c_words);
+    if (workspace_bytes < l.total) {
+        set_err("workspace too small");
+        return WAH_ERR_WORKSPACE;
+    }
+    char *ws = static_cast<char *>(d_workspace);
+    uint64_t *info = reinterpret_cast<uint64_t *>(ws + l.info_off);
+    // sums pass: tile bases and totals
+    const int rc = decode_common(d_comp, c_words, nullptr, 0, info, d_workspace, l.decode_bytes, stream, true, false);
+    if (rc != WAH_OK) return rc;
+    const DecodeLayout d = decode_layout(c_words);
+    wah::MergeArgs a;
+    a.comp = d_comp;
+    a.c_words = c_words;
+    a.n_tiles = d.n_tiles;
+    a.tile_base = reinterpret_cast<const uint64_t *>(ws + d.base_off);
+    a.info = info;
+    a.tile_kept = reinterpret_cast<uint64_t *>(ws + l.kept_off);
+    a.positions = reinterpret_cast<uint64_t *>(ws + l.pos_off);
+    a.out = d_out;
+    a.out_capacity = out_capacity_words;
+    a.out_words = d_out_words;
+    a.ctrl = reinterpret_cast<uint32_t *>(ws + d.ctrl_off);
+    const hipError_t e = wah::launch_merge_fills(a, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        set_err("merge kernels launch", e);
+        return WAH_ERR_HIP;
+    }
+    return WAH_OK;
+}
+
 // ---- bitwise operations on two compressed bitmaps -------------------------------------------------------------
 namespace {
 struct BitopLayout {

@@ -102,6 +102,22 @@ hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s);
 int decode_sums_grid(uint32_t *d_ctrl, hipStream_t s);
 hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t n_tiles, hipStream_t s);
 hipError_t launch_clear(void *p, size_t bytes, hipStream_t s);
+
+// wah_merge_fills_device (after the sums pass): kept-word counts per tile, their scan, scatter, count fix-up
+struct MergeArgs {
+    const uint32_t *comp;
+    uint64_t c_words;
+    uint64_t n_tiles;
+    const uint64_t *tile_base; // groups in front of every tile (sums pass)
+    const uint64_t *info;      // [decoded words, groups] (sums pass)
+    uint64_t *tile_kept;       // n_tiles + 1: kept words per tile, then their exclusive scan
+    uint64_t *positions;       // group position of every kept word (c_words entries)
+    uint32_t *out;
+    uint64_t out_capacity;
+    uint64_t *out_words;
+    uint32_t *ctrl;
+};
+hipError_t launch_merge_fills(const MergeArgs &a, hipStream_t s);
 hipError_t launch_validate(const uint32_t *comp, uint64_t c_words, const uint64_t *tile_base, const uint64_t *info, uint64_t *report,
                            uint64_t n_tiles, hipStream_t s);
 hipError_t launch_gen_uniform(uint32_t *out, uint64_t n, uint64_t seed, uint64_t thr, hipStream_t s);

@@ -1695,6 +1695,169 @@ hipError_t launch_clear(void *p, size_t bytes, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ===========================================================================
+// wah_merge_fills_device (include/wah.h): adjacent fills of the same kind become one word, empty fills disappear.
+// Tile-based like the checker: the sums pass gives every tile its group position, an in-workgroup scan gives every word
+// its own.  A word is DROPPED if it is an empty fill, or a fill whose predecessor is a non-empty fill of the same kind
+// and both lie inside one block of 2^29 groups (so that no merged count can outgrow 30 bits).  Kept words move up by
+// the number of dropped words in front of them; a kept fill's new count is the distance to the next kept word.
+// ===========================================================================
+constexpr u32 kMergeBlockShift = 29;
+
+struct MergeTile {
+    u32 w[kExpandWordsPerThread];
+    u64 p;          // group position of w[0]
+    u32 prev;       // the word in front of w[0]
+    bool have_prev;
+};
+
+__device__ __forceinline__ void merge_load_tile(const MergeArgs &a, u32 tile, u64 *s_wave_sum, u32 lane, u32 wave, MergeTile &t) {
+    const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread;
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        t.w[k] = w0 + k < a.c_words ? a.comp[w0 + k] : 0x80000000u; // past the end: nothing
+        mine += word_groups(t.w[k]);
+    }
+    const u64 incl = wave_scan_incl(mine, lane);
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    t.p = a.tile_base[tile] + (incl - mine);
+    for (u32 k = 0; k < wave; ++k) t.p += s_wave_sum[k];
+    t.have_prev = w0 > 0;
+    t.prev = w0 > 0 && w0 - 1 < a.c_words ? a.comp[w0 - 1] : 0u;
+}
+
+// is word x (at group position p, behind word prev) dropped?
+__device__ __forceinline__ bool merge_dropped(u32 x, u32 prev, bool have_prev, u64 p) {
+    if (!(x & kFillZero)) return false;
+    const u32 cnt = x & kCountMask;
+    if (cnt == 0u) return true;
+    if (!have_prev || !(prev & kFillZero)) return false;
+    const u32 pcnt = prev & kCountMask;
+    if (pcnt == 0u || ((prev ^ x) & 0x40000000u)) return false;
+    return ((p - pcnt) >> kMergeBlockShift) == ((p + cnt - 1u) >> kMergeBlockShift);
+}
+
+__global__ __launch_bounds__(kExpandThreads) void merge_count_kernel(const MergeArgs a) {
+    __shared__ u64 s_wave_sum[kExpandWaves];
+    __shared__ u32 s_kept[kExpandWaves];
+    const u32 lane = lane_id(), wave = wave_id(), tile = blockIdx.x;
+    MergeTile t;
+    merge_load_tile(a, tile, s_wave_sum, lane, wave, t);
+    const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread;
+    u32 kept = 0, prev = t.prev;
+    bool have_prev = t.have_prev;
+    u64 p = t.p;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        if (w0 + k < a.c_words) kept += !merge_dropped(t.w[k], prev, have_prev, p);
+        p += word_groups(t.w[k]);
+        prev = t.w[k];
+        have_prev = true;
+    }
+    const u32 wk = wave_sum32(kept);
+    if (lane == 0) s_kept[wave] = wk;
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_kept[tile] = (u64)s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
+}
+
+// exclusive scan of tile_kept[0 .. n_tiles) in place, total into tile_kept[n_tiles] and *out_words (one workgroup)
+__global__ __launch_bounds__(1024) void merge_scan_kernel(const MergeArgs a) {
+    __shared__ u64 s_part[16];
+    __shared__ u64 s_carry;
+    const u32 lane = lane_id(), wave = wave_id();
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < a.n_tiles; base += 1024) {
+        const u64 i = base + threadIdx.x;
+        const u64 v = i < a.n_tiles ? a.tile_kept[i] : 0;
+        const u64 incl = wave_scan_incl(v, lane);
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        u64 excl = incl - v + s_carry;
+        for (u32 k = 0; k < wave; ++k) excl += s_part[k];
+        if (i < a.n_tiles) a.tile_kept[i] = excl;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = excl + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const u64 total = s_carry;
+        a.tile_kept[a.n_tiles] = total;
+        *a.out_words = total;
+        if (total > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+    }
+}
+
+__global__ __launch_bounds__(kExpandThreads) void merge_scatter_kernel(const MergeArgs a) {
+    __shared__ u64 s_wave_sum[kExpandWaves];
+    __shared__ u32 s_kept[kExpandWaves];
+    const u32 lane = lane_id(), wave = wave_id(), tile = blockIdx.x;
+    MergeTile t;
+    merge_load_tile(a, tile, s_wave_sum, lane, wave, t);
+    const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread;
+    bool keep[kExpandWordsPerThread];
+    u64 pos[kExpandWordsPerThread];
+    u32 kept = 0, prev = t.prev;
+    bool have_prev = t.have_prev;
+    u64 p = t.p;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        keep[k] = w0 + k < a.c_words && !merge_dropped(t.w[k], prev, have_prev, p);
+        pos[k] = p;
+        kept += keep[k];
+        p += word_groups(t.w[k]);
+        prev = t.w[k];
+        have_prev = true;
+    }
+    const u32 incl = wave_scan_incl32(kept);
+    if (lane == 63) s_kept[wave] = incl;
+    __syncthreads();
+    u64 idx = a.tile_kept[tile] + (incl - kept);
+    for (u32 k = 0; k < wave; ++k) idx += s_kept[k];
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        if (keep[k]) {
+            if (idx < a.out_capacity) {
+                a.out[idx] = t.w[k];
+                a.positions[idx] = pos[k];
+            }
+            ++idx;
+        }
+    }
+}
+
+// a kept fill covers everything up to the next kept word
+__global__ void merge_fix_kernel(const MergeArgs a) {
+    const u64 kept = a.tile_kept[a.n_tiles] < a.out_capacity ? a.tile_kept[a.n_tiles] : a.out_capacity;
+    const u64 groups = a.info[1];
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < kept; i += (u64)gridDim.x * blockDim.x) {
+        const u32 x = a.out[i];
+        if ((x & kFillZero) && (x & kCountMask)) {
+            const u64 next = i + 1 < a.tile_kept[a.n_tiles] && i + 1 < a.out_capacity ? a.positions[i + 1] : groups;
+            const u64 cnt = next - a.positions[i];
+            if (cnt > kCountMask)
+                atomicOr(a.ctrl + kCtlError, kErrStream); // cannot happen: runs do not cross 2^29-group blocks
+            else if ((u32)cnt != (x & kCountMask))
+                a.out[i] = (x & ~kCountMask) | (u32)cnt;
+        }
+    }
+}
+
+hipError_t launch_merge_fills(const MergeArgs &a, hipStream_t s) {
+    if (a.n_tiles == 0) {
+        hipLaunchKernelGGL(clear_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<u32 *>(a.out_words), (u64)2);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(merge_count_kernel, dim3((unsigned)a.n_tiles), dim3(kExpandThreads), 0, s, a);
+    hipLaunchKernelGGL(merge_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(merge_scatter_kernel, dim3((unsigned)a.n_tiles), dim3(kExpandThreads), 0, s, a);
+    hipLaunchKernelGGL(merge_fix_kernel, dim3(2048), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+
 hipError_t launch_gen_uniform(u32 *out, u64 n, u64 seed, u64 thr, hipStream_t s) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(gen_uniform_kernel, dim3(4096), dim3(256), 0, s, out, n, seed, thr);

@@ -141,6 +141,20 @@ int wah_validate_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_re
                         size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Unsegmented ("canonical") WAH.  compress() never lets a fill cross a 1024-group segment
+ * (the reference's block structure, kernels.cu:68, tests.cpp:166-172): a long run costs one word per segment.
+ * wah_merge_fills_device rewrites a stream with adjacent fills of the same kind merged into one word (and fills of
+ * count 0 dropped), which turns the output of compress() into the classic unsegmented WAH form; the result decodes
+ * to the same bitmap with wah_decompress* (whose decoder takes fills of any length), but it is no longer what the
+ * reference's encoder would emit.  Runs are not merged across multiples of 2^29 groups, so every count fits 30 bits.
+ *   d_out: capacity c_words is always enough.  Workspace: wah_merge_fills_workspace_bytes(c_words), 256-byte aligned.
+ *   d_out_words: device uint64.  Errors are read back with wah_decompress_status(d_workspace, stream).
+ * ------------------------------------------------------------------------- */
+size_t wah_merge_fills_workspace_bytes(uint64_t c_words);
+int wah_merge_fills_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
+                           uint64_t *d_out_words, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Bitwise operations on two compressed bitmaps (not in the reference, whose README.md:10
  * names them as the reason bitmap indexes use WAH).  Both streams must describe bitmaps of n_words words.  The
  * result is what compress() gives for (A op B): decode A, decode B (decode_sums + decode_expand each) into scratch,

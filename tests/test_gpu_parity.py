@@ -293,6 +293,48 @@ def test_validate_streams(wah, oracle):
     assert tuple(wah.validate_device(_dev(np.zeros(0, np.uint32)))) == (0, 0, 0, 0, 0, 0, True)
 
 
+# ---------------------------------------------------------------- unsegmented form
+def _py_merge_fills(st):
+    """Word-by-word restatement of wah_merge_fills_device: drop empty fills; drop a fill whose immediate predecessor is a
+    non-empty fill of the same kind inside the same block of 2^29 groups; a kept fill runs to the next kept word."""
+    kept, pos = [], []
+    p = 0
+    prev = None
+    for x in (int(v) for v in st):
+        fill, cnt = bool(x & 0x80000000), x & 0x3FFFFFFF
+        drop = False
+        if fill and cnt == 0:
+            drop = True
+        elif fill and prev is not None and (prev & 0x80000000) and (prev & 0x3FFFFFFF) and not ((prev ^ x) & 0x40000000):
+            drop = ((p - (prev & 0x3FFFFFFF)) >> 29) == ((p + cnt - 1) >> 29)
+        if not drop:
+            kept.append(x)
+            pos.append(p)
+        p += cnt if fill else 1
+        prev = x
+    pos.append(p)
+    out = [(x & 0xC0000000) | (pos[i + 1] - pos[i]) if (x & 0x80000000) and (x & 0x3FFFFFFF) else x for i, x in enumerate(kept)]
+    return np.array(out, np.uint32)
+
+
+def test_merge_fills_unsegmented_form(wah, oracle):
+    rng = np.random.default_rng(8)
+    cases = [oracle.compress(np.zeros(992 * 700 + 3, np.uint32)), oracle.compress(oracle.gen_uniform(992 * 900, 2, 2.0**-14)),
+             oracle.compress(oracle.gen_clustered(992 * 600 + 11, 3, 50000)), oracle.compress(oracle.gen_uniform(992 * 40, 4, 0.3)),
+             _random_foreign_stream(rng, 4096 * 3 + 9, 30_000_000), np.zeros(0, np.uint32),
+             np.array([0x80000000 | ((1 << 29) - 4), 0x80000000 | 8, 0x80000000 | 9, 0xC0000000 | 1, 0xC0000000, 0xC0000000 | 2], np.uint32)]
+    for st in cases:
+        got = _host(wah.merge_fills_device(_dev(st)))
+        assert np.array_equal(got, _py_merge_fills(st))
+        if len(st) and oracle.decoded_groups(st) < 40_000_000:
+            assert np.array_equal(oracle.decompress(got), oracle.decompress(st))
+    # an all-zero bitmap: one word per segment before, one word after
+    z = oracle.compress(np.zeros(992 * 700, np.uint32))
+    assert len(z) == 700 and np.array_equal(_host(wah.merge_fills_device(_dev(z))), [0x80000000 | 700 * 1024])
+    # the merged stream is no longer what the reference's encoder emits, and the checker says so
+    assert not wah.validate_device(wah.merge_fills_device(_dev(z))).segment_canonical
+
+
 # ---------------------------------------------------------------- bitwise operations on compressed bitmaps
 def test_bitops_on_compressed_bitmaps(wah, oracle):
     """wah_bitop_device(op, A, B) == compress(decompress(A) op decompress(B)), for whole-segment and ragged lengths."""
