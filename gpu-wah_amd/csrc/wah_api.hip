@@ -66,11 +66,13 @@ DecodeLayout decode_layout(uint64_t c_words) {
     return l;
 }
 
-int read_status(void *d_workspace, void *stream) {
+// status word of a launch, and optionally `n_vals` 64-bit results of it, in ONE round trip to the device
+int read_status(void *d_workspace, void *stream, const uint64_t *d_vals = nullptr, uint64_t *vals = nullptr, int n_vals = 0) {
     uint32_t err = 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipError_t e = hipMemcpyAsync(&err, static_cast<uint32_t *>(d_workspace) + wah::kCtlError, sizeof err,
                                   hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && n_vals) e = hipMemcpyAsync(vals, d_vals, n_vals * sizeof(uint64_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) {
         set_err("status read-back", e);
@@ -565,13 +567,12 @@ uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *ou
     hc.start();
     int rc = wah_compress_device(static_cast<uint32_t *>(d_in), n_words, static_cast<uint32_t *>(d_out), cap,
                                  static_cast<uint64_t *>(d_cnt), d_ws, ws_bytes, nullptr);
-    if (rc == WAH_OK) rc = wah_compress_status(d_ws, nullptr);
+    uint64_t c = 0;
+    if (rc == WAH_OK) rc = read_status(d_ws, nullptr, static_cast<const uint64_t *>(d_cnt), &c, 1); // status + size: one sync
     if (rc != WAH_OK) {
         std::fprintf(stderr, "wah: compress failed: %s\n", g_err);
         return nullptr;
     }
-    uint64_t c = 0;
-    if (!hip_ok(hipMemcpy(&c, d_cnt, sizeof c, hipMemcpyDeviceToHost), "copy output size")) return nullptr;
     t_dev = hc.stop();
 
     // phase 3: D2H + free (compress.cu:177-202)
@@ -626,10 +627,8 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     hc.start();
     int rc = wah_decompress_scan_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint64_t *>(d_info), d_ws0,
                                         ws0, nullptr);
-    if (rc == WAH_OK) rc = wah_decompress_status(d_ws0, nullptr);
     uint64_t info[2] = {0, 0};
-    if (rc == WAH_OK && !hip_ok(hipMemcpy(info, d_info, sizeof info, hipMemcpyDeviceToHost), "copy output size"))
-        rc = WAH_ERR_HIP;
+    if (rc == WAH_OK) rc = read_status(d_ws0, nullptr, static_cast<const uint64_t *>(d_info), info, 2); // status + sizes: one sync
     if (rc != WAH_OK) {
         std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
         return nullptr;
