@@ -1873,7 +1873,7 @@ hipError_t launch_gen_clustered(u32 *out, u64 n, u64 seed, u64 thr, hipStream_t 
 hipError_t launch_copy(const u32 *in, u32 *out, u64 n, hipStream_t s) {
     const u64 n16 = n / 4;
     if (n16 == 0) return hipSuccess;
-    hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, s, reinterpret_cast<const uint4 *>(in),
+    hipLaunchKernelGGL(copy_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const uint4 *>(in),
                        reinterpret_cast<uint4 *>(out), n16);
     return hipGetLastError();
 }
