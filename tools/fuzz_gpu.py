@@ -25,6 +25,13 @@ for seed in range(nd):
         bad += 1
         d = np.nonzero(got[: min(len(got), len(want))] != want[: min(len(got), len(want))])[0]
         print("DECODE MISMATCH seed", seed, "words", len(st), "len", len(got), len(want), "first diffs", d[:5])
+    if len(st) <= 20000:  # the word-by-word Python restatements are slow
+        if tuple(wah.validate_device(T._dev(st))) != T._py_report(st):
+            bad += 1
+            print("VALIDATE MISMATCH seed", seed)
+        if not np.array_equal(T._host(wah.merge_fills_device(T._dev(st))), T._py_merge_fills(st)):
+            bad += 1
+            print("MERGE MISMATCH seed", seed)
     if seed % 20 == 0:
         print("decode seed", seed, "ok so far, bad =", bad, f"{time.time() - t0:.0f}s", flush=True)
 for seed in range(nc):
@@ -48,6 +55,14 @@ for seed in range(nc):
     if not np.array_equal(back[:n], data):
         bad += 1
         print("ROUND TRIP MISMATCH seed", seed, "n", n, "mode", mode)
+    if n >= 992 and seed % 3 == 0:  # bitwise operations against numpy on the decoded bitmaps
+        other = oracle.gen_clustered(n, seed + 7, 900)
+        for name, fn in (("and", np.bitwise_and), ("or", np.bitwise_or), ("xor", np.bitwise_xor), ("andnot", lambda x, y: x & ~y)):
+            w = oracle.compress(fn(data, other).astype(np.uint32))
+            g = T._host(wah.bitop_device(name, T._dev(want), T._dev(oracle.compress(other)), n))
+            if g.shape != w.shape or not np.array_equal(g, w):
+                bad += 1
+                print("BITOP MISMATCH seed", seed, name, "n", n)
     if seed % 10 == 0:
         print("compress seed", seed, "bad =", bad, f"{time.time() - t0:.0f}s", flush=True)
 print("done, mismatches:", bad)
