@@ -50,7 +50,7 @@ CompressLayout compress_layout(uint64_t n_words) {
 
 struct DecodeLayout {
     uint64_t n_tiles;
-    size_t ctrl_off, desc_off, big_off, base_off, total, zero_bytes;
+    size_t ctrl_off, desc_off, big_off, base_off, flags_off, total, zero_bytes;
 };
 
 DecodeLayout decode_layout(uint64_t c_words) {
@@ -62,7 +62,8 @@ DecodeLayout decode_layout(uint64_t c_words) {
     l.zero_bytes = round256(l.desc_off + (4 * l.n_tiles + 8) * sizeof(uint32_t));
     l.big_off = l.zero_bytes;
     l.base_off = round256(l.big_off + (l.n_tiles + 1) * sizeof(uint64_t));
-    l.total = round256(l.base_off + (l.n_tiles + 4) * sizeof(uint64_t)); // + two words for wah_validate_device
+    l.flags_off = round256(l.base_off + (l.n_tiles + 4) * sizeof(uint64_t)); // (+ two words for wah_validate_device)
+    l.total = round256(l.flags_off + l.n_tiles + 16);                       // one byte per tile: contains empty fills
     return l;
 }
 
@@ -310,6 +311,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
             a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
             a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
             a.big = reinterpret_cast<uint64_t *>(ws + l.big_off);
+            a.tile_flags = reinterpret_cast<uint8_t *>(ws + l.flags_off);
             a.aligned16 = aligned16(d_comp) ? 1 : 0;
             a.census = 0;
             e = wah::launch_decode_sums(a, (int)grid64, s);
@@ -328,6 +330,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         x.out_capacity = out_capacity_words;
         x.info = d_out_info;
         x.tile_base = reinterpret_cast<const uint64_t *>(ws + l.base_off);
+        x.tile_flags = reinterpret_cast<const uint8_t *>(ws + l.flags_off);
         x.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
         x.aligned16 = aligned16(d_comp) ? 1 : 0;
         x.parts = 1; // the launcher decides

@@ -23,7 +23,6 @@ constexpr uint32_t kSteps = 16; // 64 groups (one wavefront) per step
 constexpr uint32_t kCtlStart = 0;        // arrival ticket: order in which workgroups start running
 constexpr uint32_t kCtlError = 160;      // sticky error bits
 constexpr uint32_t kCtlCensus = 161;     // census mode: workgroups resident together
-constexpr uint32_t kCtlFlags = 162;      // decode: bit 0 = the stream contains fill words of count 0
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
 constexpr uint32_t kErrTimeout = 1u;     // a bounded wait expired
 constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity
@@ -69,6 +68,7 @@ struct ScanArgs {
     uint32_t *ctrl;
     uint32_t *gen_desc;  // generation rows (4-byte granules)
     uint64_t *big;       // 64-bit side entries for totals that do not fit a granule
+    uint8_t *tile_flags; // n_tiles: 1 = the tile contains a fill word of count 0
     int aligned16;
     int census;
 };
@@ -80,6 +80,7 @@ struct ExpandArgs {
     uint64_t out_capacity;
     const uint64_t *info;
     const uint64_t *tile_base;
+    const uint8_t *tile_flags; // from the sums pass: tiles with fill words of count 0
     uint32_t *ctrl;
     int aligned16;
     uint32_t parts; // workgroups that share one tile's output segments (set by the launcher)

@@ -1020,11 +1020,11 @@ __global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(con
     // worker waves: stream one expand tile per iteration, sum the group counts (getCounts, kernels.cu:291-309)
     uint4 pre[4];
     // A fill word of count 0 expands to nothing; the reference decoder steps over it (kernels.cu:332-354).  The
-    // expand kernel's rank arithmetic assumes that every word owns at least one group, so the stream is checked
-    // here and expand takes its general (slower) route when one is found.  `pre_whole`: the prefetched round consists
-    // of real words only (no padding past the end, which is written as empty fills).
-    bool saw_empty = false, pre_whole = true;
-    u32 n_min = 1;
+    // expand kernel's rank arithmetic assumes that every word owns at least one group, so every tile is checked here
+    // and expand takes its index-map route for the tiles concerned (tile_flags).  `pre_whole`: the prefetched round
+    // consists of real words only (no padding past the end, which is written as empty fills); `pre_empty`: a round
+    // that needed bounds checks contains an empty fill among its real words.
+    bool pre_empty = false, pre_whole = true;
     // round `rd` (0..3) of expand tile `et`: 1024 words as four fully coalesced 1 KiB loads (order is irrelevant)
     auto load_round = [&](u32 et, u32 rd) {
         const u64 w0 = (u64)et * kScanTileWords + (u64)rd * 1024u;
@@ -1033,14 +1033,16 @@ __global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(con
 #pragma unroll
             for (int k = 0; k < 4; ++k) pre[k] = src[k * 64 + (int)lane];
             pre_whole = true;
+            pre_empty = false;
         } else {
             u32 t[16];
             pre_whole = false;
+            pre_empty = false;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const u64 i = w0 + (u64)(k / 4) * 256u + (u64)lane * 4u + (u64)(k % 4);
                 t[k] = i < a.c_words ? a.comp[i] : 0x80000000u; // past the end: a fill of zero groups
-                saw_empty |= i < a.c_words && word_groups(t[k]) == 0u;
+                pre_empty |= i < a.c_words && word_groups(t[k]) == 0u;
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) pre[k] = make_uint4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
@@ -1051,12 +1053,14 @@ __global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(con
     for (u32 wt = arrival; wt < n_wg_tiles; wt += stride, ++gen) {
         const u32 et = wt * (u32)kSumWorkers + wave;
         u64 mine = 0;
+        bool tile_empty = false;
 #pragma unroll
         for (u32 rd = 0; rd < 4; ++rd) {
             uint4 cur[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) cur[k] = pre[k];
             const bool cur_whole = pre_whole;
+            tile_empty |= pre_empty;
             // rolling prefetch: next round of this tile, or round 0 of this wave's next tile
             if (rd < 3)
                 load_round(et, rd + 1);
@@ -1069,7 +1073,11 @@ __global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(con
                 mine += (u64)(nx + ny + nz + nw);
                 round_min = min(min(round_min, min(nx, ny)), min(nz, nw));
             }
-            if (cur_whole) n_min = min(n_min, round_min);
+            if (cur_whole) tile_empty |= round_min == 0u;
+        }
+        {
+            const bool any_empty = __any(tile_empty);
+            if (lane == 0 && (u64)et < a.n_tiles) a.tile_flags[et] = any_empty ? 1 : 0;
         }
         const u64 wave_total = uniform64(wave_sum(mine));
         const u32 q = gen & 3u;
@@ -1101,7 +1109,6 @@ __global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(con
             }
         }
     }
-    if (__any(saw_empty || n_min == 0u) && lane == 0) atomicOr(a.ctrl + kCtlFlags, 1u);
 }
 
 // ---------------------------------------------------------------------------
@@ -1434,9 +1441,11 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
     u64 k_end = (base + total + kSegGroups - 1) / kSegGroups;
     if (k_end > n_seg) k_end = n_seg;
 
-    if (a.ctrl[kCtlFlags] & 1u) {
-        // the stream contains fill words of count 0 (found by the sums pass): general route, one wavefront per
-        // workgroup, the four flag areas together hold its 1024-entry index map
+    const u64 all_tiles = (a.c_words + kScanTileWords - 1) / kScanTileWords;
+    if (a.tile_flags[tile] | ((u64)tile + 1 < all_tiles ? a.tile_flags[tile + 1] : 0)) {
+        // this tile, or the next one (a segment reads at most 1024 + 128 words past its tile), contains fill words of
+        // count 0 (found by the sums pass): index-map route, one wavefront per workgroup, the four flag areas together
+        // hold its 1024-entry index map
         static_assert(sizeof(s_flag) >= kSegGroups * sizeof(u32), "index map must fit the flag areas");
         if (wave == 0)
             for (u64 seg = k_begin + part; seg < k_end; seg += a.parts)
