@@ -446,7 +446,7 @@ __device__ __forceinline__ void lds_publish(u32 *flag, u32 value) {
 }
 // A waiting wave must not compete with the working ones: the hardware favours the OLDEST wave of a SIMD, and the
 // oldest waves are exactly the ones that finish first and wait (measured: a busy spin made the youngest worker of a
-// SIMD take 1.75x as long as the oldest).  So: lowest priority and long sleeps while waiting.
+// SIMD take 1.75x as long as the oldest).  So: lowest priority and a short sleep between polls (128 cycles; longer ones only delay the hand-over).
 __device__ __forceinline__ bool lds_wait(const u32 *flag, u32 value, u32 *ctrl, u32 lane) {
     if (lds_ld(flag) != value) {
         __builtin_amdgcn_s_setprio(0);
@@ -456,7 +456,7 @@ __device__ __forceinline__ bool lds_wait(const u32 *flag, u32 value, u32 *ctrl, 
                 __builtin_amdgcn_s_setprio(1);
                 return false;
             }
-            __builtin_amdgcn_s_sleep(6);
+            __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_s_setprio(1);
     }
@@ -473,7 +473,7 @@ __device__ __forceinline__ bool lds_wait_reached(const u32 *counter, u32 value, 
                 atomicOr(ctrl + kCtlError, kErrTimeout);
                 return false;
             }
-            __builtin_amdgcn_s_sleep(6);
+            __builtin_amdgcn_s_sleep(2);
         }
         __builtin_amdgcn_s_setprio(1);
     }
