@@ -1387,6 +1387,9 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
     const u64 tile_w0 = (u64)tile * kScanTileWords;
     const u64 groups = a.info[1];
     const u64 out_words = a.info[0];
+    // (asked for up front, used after the prologue: this tile or the next one contains fill words of count 0)
+    const u64 all_tiles = (a.c_words + kScanTileWords - 1) / kScanTileWords;
+    const bool has_empties = (a.tile_flags[tile] | ((u64)tile + 1 < all_tiles ? a.tile_flags[tile + 1] : 0)) != 0;
     if (out_words > a.out_capacity) {
         if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
         return;
@@ -1441,8 +1444,7 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
     u64 k_end = (base + total + kSegGroups - 1) / kSegGroups;
     if (k_end > n_seg) k_end = n_seg;
 
-    const u64 all_tiles = (a.c_words + kScanTileWords - 1) / kScanTileWords;
-    if (a.tile_flags[tile] | ((u64)tile + 1 < all_tiles ? a.tile_flags[tile + 1] : 0)) {
+    if (has_empties) {
         // this tile, or the next one (a segment reads at most 1024 + 128 words past its tile), contains fill words of
         // count 0 (found by the sums pass): index-map route, one wavefront per workgroup, the four flag areas together
         // hold its 1024-entry index map
