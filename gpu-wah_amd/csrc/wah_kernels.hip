@@ -17,6 +17,11 @@
 //     thrust::exclusive_scan + moveData (compress.cu:133-166, kernels.cu:273-280);
 //   * tiles are assigned round robin to the workgroups in arrival order, the grid is sized from a residency census
 //     of the kernel itself, and every wait is bounded: a lost workgroup ends in WAH_ERR_TIMEOUT, never in a hang.
+//
+// Sections of this file, in order: wavefront helpers and the generation scan; compress (staging, the classify block
+// -- csrc/classify_block*.inc --, compress_kernel); decompress (decode_sums_kernel, the expand routines,
+// decode_expand_kernel); stream checker; generators / copy used by the bench; launchers; workspace clearing; the
+// merge pass of wah_merge_fills_device.
 #include "wah_internal.hpp"
 
 #include "../../include/wah_gen.h"
