@@ -1,0 +1,298 @@
+// wah_aux.hip -- around the path: stream checker, bench generators / copy, workspace clearing, the merge pass of
+// wah_merge_fills_device (the shared wavefront helpers are in wah_device.hpp)
+#include "wah_device.hpp"
+
+#include "../../include/wah_gen.h"
+
+namespace wah {
+namespace {
+
+// ===========================================================================
+// stream checker (include/wah.h: wah_validate_device).  One workgroup per 4096-word tile, after the sums pass: the
+// tile bases give every word its group position, so the per-word properties that depend on position (a fill crossing
+// a 1024-group boundary, two mergeable fills inside one segment) can be told from the ones that do not.
+// ===========================================================================
+__global__ __launch_bounds__(kExpandThreads) void validate_kernel(const u32 *comp, u64 c_words, const u64 *tile_base,
+                                                                  const u64 *info, u64 *report) {
+    __shared__ u64 s_wave_sum[kExpandWaves];
+    const u32 lane = lane_id();
+    const u32 wave = wave_id();
+    const u32 tile = blockIdx.x;
+    const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread; // my 16 consecutive words
+    u32 w[kExpandWordsPerThread];
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        w[k] = w0 + k < c_words ? comp[w0 + k] : 0x80000000u; // past the end: nothing
+        mine += word_groups(w[k]);
+    }
+    const u64 incl = wave_scan_incl(mine, lane);
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    u64 p = tile_base[tile] + (incl - mine); // group position of my first word
+    for (u32 k = 0; k < wave; ++k) p += s_wave_sum[k];
+
+    u32 prev = w0 > 0 && w0 - 1 < c_words ? comp[w0 - 1] : 0u; // the word in front of mine (a literal 0 if none)
+    const bool have_prev = w0 > 0;
+    u32 n_empty = 0, n_litfill = 0, n_cross = 0, n_unmerged = 0;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        const u32 x = w[k];
+        if (w0 + k < c_words) {
+            const bool fill = (x & kFillZero) != 0;
+            const u32 cnt = x & kCountMask;
+            n_empty += fill && cnt == 0u;
+            n_litfill += !fill && (x == 0u || x == kOnes31);
+            n_cross += fill && cnt != 0u && (p & (kSegGroups - 1u)) + cnt > kSegGroups;
+            const bool prev_fill = (k > 0 || have_prev) && (prev & kFillZero) && (prev & kCountMask) != 0u;
+            n_unmerged += fill && cnt != 0u && prev_fill && ((prev ^ x) & 0x40000000u) == 0u && (p & (kSegGroups - 1u)) != 0u;
+        }
+        p += word_groups(x);
+        prev = x;
+    }
+    const u32 t_empty = wave_sum32(n_empty), t_lit = wave_sum32(n_litfill), t_cross = wave_sum32(n_cross), t_unm = wave_sum32(n_unmerged);
+    if (lane == 0) {
+        if (t_empty) atomicAdd(reinterpret_cast<unsigned long long *>(report + 2), (unsigned long long)t_empty);
+        if (t_lit) atomicAdd(reinterpret_cast<unsigned long long *>(report + 3), (unsigned long long)t_lit);
+        if (t_cross) atomicAdd(reinterpret_cast<unsigned long long *>(report + 4), (unsigned long long)t_cross);
+        if (t_unm) atomicAdd(reinterpret_cast<unsigned long long *>(report + 5), (unsigned long long)t_unm);
+        if (t_empty | t_lit | t_cross | t_unm) report[6] = 0; // (set to 1 by validate_init_kernel)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        report[0] = info[1];
+        report[1] = info[0];
+    }
+}
+
+__global__ void validate_init_kernel(u64 *report) {
+    if (threadIdx.x < 8) report[threadIdx.x] = threadIdx.x == 6 ? 1ull : 0ull;
+}
+
+// ===========================================================================
+// bench support
+// ===========================================================================
+__global__ void gen_uniform_kernel(u32 *out, u64 n, u64 seed, u64 thr) {
+    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n; w += (u64)gridDim.x * blockDim.x)
+        out[w] = wah_gen_uniform_word(seed, w, thr);
+}
+
+__global__ void gen_clustered_kernel(u32 *out, u64 n, u64 seed, u64 thr) {
+    const u64 chunks = (n + WAH_GEN_CHUNK_WORDS - 1) / WAH_GEN_CHUNK_WORDS;
+    for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += (u64)gridDim.x * blockDim.x) {
+        const u64 w0 = c * WAH_GEN_CHUNK_WORDS;
+        const u64 left = n - w0;
+        wah_gen_clustered_chunk(seed, c, thr, out + w0, (u32)(left < WAH_GEN_CHUNK_WORDS ? left : WAH_GEN_CHUNK_WORDS));
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const uint4 *in, uint4 *out, u64 n16) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (u64)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+} // namespace
+
+hipError_t launch_validate(const u32 *comp, u64 c_words, const u64 *tile_base, const u64 *info, u64 *report, u64 n_tiles,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(validate_init_kernel, dim3(1), dim3(64), 0, s, report);
+    if (n_tiles) hipLaunchKernelGGL(validate_kernel, dim3((unsigned)n_tiles), dim3(kExpandThreads), 0, s, comp, c_words, tile_base, info, report);
+    return hipGetLastError();
+}
+
+// Zero `bytes` bytes (a multiple of 4) at p (4-byte aligned).  A kernel of our own rather than hipMemsetAsync: the
+// device-pointer API is meant to be captured into HIP graphs, and a captured memset node did not reliably write
+// zeros when the graph was replayed (ROCm 7.2, observed on MI355X: tests/test_gpu_parity.py graph test).
+__global__ void clear_kernel(u32 *p, u64 n_words) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (u64)gridDim.x * blockDim.x) p[i] = 0u;
+}
+hipError_t launch_clear(void *p, size_t bytes, hipStream_t s) {
+    const u64 n = bytes / 4;
+    if (n == 0) return hipSuccess;
+    const u64 blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(clear_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, s, static_cast<u32 *>(p), n);
+    return hipGetLastError();
+}
+
+// ===========================================================================
+// wah_merge_fills_device (include/wah.h): adjacent fills of the same kind become one word, empty fills disappear.
+// Tile-based like the checker: the sums pass gives every tile its group position, an in-workgroup scan gives every word
+// its own.  A word is DROPPED if it is an empty fill, or a fill whose predecessor is a non-empty fill of the same kind
+// and both lie inside one block of 2^29 groups (so that no merged count can outgrow 30 bits).  Kept words move up by
+// the number of dropped words in front of them; a kept fill's new count is the distance to the next kept word.
+// ===========================================================================
+constexpr u32 kMergeBlockShift = 29;
+
+struct MergeTile {
+    u32 w[kExpandWordsPerThread];
+    u64 p;          // group position of w[0]
+    u32 prev;       // the word in front of w[0]
+    bool have_prev;
+};
+
+__device__ __forceinline__ void merge_load_tile(const MergeArgs &a, u32 tile, u64 *s_wave_sum, u32 lane, u32 wave, MergeTile &t) {
+    const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread;
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        t.w[k] = w0 + k < a.c_words ? a.comp[w0 + k] : 0x80000000u; // past the end: nothing
+        mine += word_groups(t.w[k]);
+    }
+    const u64 incl = wave_scan_incl(mine, lane);
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    t.p = a.tile_base[tile] + (incl - mine);
+    for (u32 k = 0; k < wave; ++k) t.p += s_wave_sum[k];
+    t.have_prev = w0 > 0;
+    t.prev = w0 > 0 && w0 - 1 < a.c_words ? a.comp[w0 - 1] : 0u;
+}
+
+// is word x (at group position p, behind word prev) dropped?
+__device__ __forceinline__ bool merge_dropped(u32 x, u32 prev, bool have_prev, u64 p) {
+    if (!(x & kFillZero)) return false;
+    const u32 cnt = x & kCountMask;
+    if (cnt == 0u) return true;
+    if (!have_prev || !(prev & kFillZero)) return false;
+    const u32 pcnt = prev & kCountMask;
+    if (pcnt == 0u || ((prev ^ x) & 0x40000000u)) return false;
+    return ((p - pcnt) >> kMergeBlockShift) == ((p + cnt - 1u) >> kMergeBlockShift);
+}
+
+__global__ __launch_bounds__(kExpandThreads) void merge_count_kernel(const MergeArgs a) {
+    __shared__ u64 s_wave_sum[kExpandWaves];
+    __shared__ u32 s_kept[kExpandWaves];
+    const u32 lane = lane_id(), wave = wave_id(), tile = blockIdx.x;
+    MergeTile t;
+    merge_load_tile(a, tile, s_wave_sum, lane, wave, t);
+    const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread;
+    u32 kept = 0, prev = t.prev;
+    bool have_prev = t.have_prev;
+    u64 p = t.p;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        if (w0 + k < a.c_words) kept += !merge_dropped(t.w[k], prev, have_prev, p);
+        p += word_groups(t.w[k]);
+        prev = t.w[k];
+        have_prev = true;
+    }
+    const u32 wk = wave_sum32(kept);
+    if (lane == 0) s_kept[wave] = wk;
+    __syncthreads();
+    if (threadIdx.x == 0) a.tile_kept[tile] = (u64)s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
+}
+
+// exclusive scan of tile_kept[0 .. n_tiles) in place, total into tile_kept[n_tiles] and *out_words (one workgroup)
+__global__ __launch_bounds__(1024) void merge_scan_kernel(const MergeArgs a) {
+    __shared__ u64 s_part[16];
+    __shared__ u64 s_carry;
+    const u32 lane = lane_id(), wave = wave_id();
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < a.n_tiles; base += 1024) {
+        const u64 i = base + threadIdx.x;
+        const u64 v = i < a.n_tiles ? a.tile_kept[i] : 0;
+        const u64 incl = wave_scan_incl(v, lane);
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        u64 excl = incl - v + s_carry;
+        for (u32 k = 0; k < wave; ++k) excl += s_part[k];
+        if (i < a.n_tiles) a.tile_kept[i] = excl;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = excl + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const u64 total = s_carry;
+        a.tile_kept[a.n_tiles] = total;
+        *a.out_words = total;
+        if (total > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+    }
+}
+
+__global__ __launch_bounds__(kExpandThreads) void merge_scatter_kernel(const MergeArgs a) {
+    __shared__ u64 s_wave_sum[kExpandWaves];
+    __shared__ u32 s_kept[kExpandWaves];
+    const u32 lane = lane_id(), wave = wave_id(), tile = blockIdx.x;
+    MergeTile t;
+    merge_load_tile(a, tile, s_wave_sum, lane, wave, t);
+    const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread;
+    bool keep[kExpandWordsPerThread];
+    u64 pos[kExpandWordsPerThread];
+    u32 kept = 0, prev = t.prev;
+    bool have_prev = t.have_prev;
+    u64 p = t.p;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        keep[k] = w0 + k < a.c_words && !merge_dropped(t.w[k], prev, have_prev, p);
+        pos[k] = p;
+        kept += keep[k];
+        p += word_groups(t.w[k]);
+        prev = t.w[k];
+        have_prev = true;
+    }
+    const u32 incl = wave_scan_incl32(kept);
+    if (lane == 63) s_kept[wave] = incl;
+    __syncthreads();
+    u64 idx = a.tile_kept[tile] + (incl - kept);
+    for (u32 k = 0; k < wave; ++k) idx += s_kept[k];
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        if (keep[k]) {
+            if (idx < a.out_capacity) {
+                a.out[idx] = t.w[k];
+                a.positions[idx] = pos[k];
+            }
+            ++idx;
+        }
+    }
+}
+
+// a kept fill covers everything up to the next kept word
+__global__ void merge_fix_kernel(const MergeArgs a) {
+    const u64 kept = a.tile_kept[a.n_tiles] < a.out_capacity ? a.tile_kept[a.n_tiles] : a.out_capacity;
+    const u64 groups = a.info[1];
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < kept; i += (u64)gridDim.x * blockDim.x) {
+        const u32 x = a.out[i];
+        if ((x & kFillZero) && (x & kCountMask)) {
+            const u64 next = i + 1 < a.tile_kept[a.n_tiles] && i + 1 < a.out_capacity ? a.positions[i + 1] : groups;
+            const u64 cnt = next - a.positions[i];
+            if (cnt > kCountMask)
+                atomicOr(a.ctrl + kCtlError, kErrStream); // cannot happen: runs do not cross 2^29-group blocks
+            else if ((u32)cnt != (x & kCountMask))
+                a.out[i] = (x & ~kCountMask) | (u32)cnt;
+        }
+    }
+}
+
+hipError_t launch_merge_fills(const MergeArgs &a, hipStream_t s) {
+    if (a.n_tiles == 0) {
+        hipLaunchKernelGGL(clear_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<u32 *>(a.out_words), (u64)2);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(merge_count_kernel, dim3((unsigned)a.n_tiles), dim3(kExpandThreads), 0, s, a);
+    hipLaunchKernelGGL(merge_scan_kernel, dim3(1), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(merge_scatter_kernel, dim3((unsigned)a.n_tiles), dim3(kExpandThreads), 0, s, a);
+    hipLaunchKernelGGL(merge_fix_kernel, dim3(2048), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+
+hipError_t launch_gen_uniform(u32 *out, u64 n, u64 seed, u64 thr, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gen_uniform_kernel, dim3(4096), dim3(256), 0, s, out, n, seed, thr);
+    return hipGetLastError();
+}
+
+hipError_t launch_gen_clustered(u32 *out, u64 n, u64 seed, u64 thr, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gen_clustered_kernel, dim3(1024), dim3(64), 0, s, out, n, seed, thr);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy(const u32 *in, u32 *out, u64 n, hipStream_t s) {
+    const u64 n16 = n / 4;
+    if (n16 == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const uint4 *>(in),
+                       reinterpret_cast<uint4 *>(out), n16);
+    return hipGetLastError();
+}
+
+} // namespace wah

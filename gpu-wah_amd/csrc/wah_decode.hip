@@ -1,0 +1,645 @@
+// wah_decode.hip -- decompress: decode_sums_kernel (tile bases) and decode_expand_kernel (see wah_compress.hip for the
+// conventions; the shared wavefront helpers are in wah_device.hpp)
+#include "wah_device.hpp"
+
+namespace wah {
+namespace {
+
+// ===========================================================================
+// decompress
+//
+// The reference runs getCounts -> thrust::exclusive_scan over one u64 PER COMPRESSED WORD -> decompressWords (a
+// serial fill loop per thread into a 4-byte-per-group intermediate) -> mergeWords (kernels.cu:291-385,
+// decompress.cu:66-115).  Here:
+//   pass 1  decode_sums_kernel   : streaming reduce.  Tiles of 4096 compressed words; per tile the number of 31-bit
+//                                   groups it expands to, turned into exclusive tile bases by the same one-hop
+//                                   generation scan as compress.  Reads C once, writes 8 bytes per tile.
+//   pass 2  decode_expand_kernel : one workgroup per tile, tile words resident in LDS.  A tile OWNS the output
+//                                   segments (1024 groups -> 992 words) whose first group falls into it; each of its
+//                                   wavefronts expands whole segments: group -> source word by RANK (mbcnt over a
+//                                   1024-bit mask of word starts), fill / literal decode, 31 -> 32 repack in
+//                                   registers with two DPP shifts, dense 248-byte stores.
+// Any stream the reference decoder accepts is handled (arbitrary 30-bit counts, fills across segment boundaries).
+// ===========================================================================
+constexpr u32 kGenEscape = 0x7FFFFFFFu; // granule value: "total does not fit 31 bits, read the 64-bit side entry"
+
+// generation scan with 64-bit totals (a tile of fills can expand to more than 2^31 groups)
+__device__ __forceinline__ u64 resolve_generation64(const u32 *gdesc, const u64 *big, u32 gen, u32 slot, u32 G,
+                                                    u32 row_stride, u64 aggregate, GenScan &st, u64 &own_prev64,
+                                                    u64 &below_prev64, u32 lane, u32 *ctrl) {
+    const u32 *cur = gdesc + (u64)gen * row_stride;
+    const u32 *prv = cur - row_stride;
+    bool need_prev = gen > 0 && slot + 1 < G, need_cur = slot > 0;
+    u64 above = 0, below = 0;
+    u32 spins = 0;
+    while (need_prev || need_cur) {
+        u64 sum_cur = 0, sum_prev = 0;
+        bool bad_cur = false, bad_prev = false;
+        for (u32 k = lane; k < G; k += 64u) {
+            if (need_cur && k < slot) {
+                const u32 e = __hip_atomic_load(cur + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad_cur |= !(e & kGenValid);
+                u64 v = e & ~kGenValid;
+                if (v == kGenEscape && (e & kGenValid))
+                    v = __hip_atomic_load(big + ((u64)gen * G + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sum_cur += v;
+            }
+            if (need_prev && k > slot) {
+                const u32 e = __hip_atomic_load(prv + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bad_prev |= !(e & kGenValid);
+                u64 v = e & ~kGenValid;
+                if (v == kGenEscape && (e & kGenValid))
+                    v = __hip_atomic_load(big + ((u64)(gen - 1) * G + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sum_prev += v;
+            }
+        }
+        bool progressed = false;
+        if (need_cur && !__any(bad_cur)) {
+            below = uniform64(wave_sum(sum_cur));
+            need_cur = false;
+            progressed = true;
+        }
+        if (need_prev && !__any(bad_prev)) {
+            above = uniform64(wave_sum(sum_prev));
+            need_prev = false;
+            progressed = true;
+        }
+        if (!progressed) {
+            if (++spins > kMaxSpins) {
+                if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    if (gen > 0) st.gen_base += below_prev64 + own_prev64 + above;
+    below_prev64 = below;
+    own_prev64 = aggregate;
+    return st.gen_base + below;
+}
+
+// Workgroup = kSumWorkers worker wavefronts + 1 scan wave.  A worker sums one whole expand tile (4096 words) per
+// iteration in four rolling 4 KiB rounds; the workgroup's tile (kSumWorkers expand tiles, 128 KiB) costs ONE
+// granule, so the scan traffic stays below 1 % of the stream.
+constexpr int kSumWorkers = kSumTilesPerGroup;
+
+__global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(const ScanArgs a) {
+    __shared__ u64 s_part[4][kSumWorkers];
+    __shared__ u32 s_arrived[4];
+    __shared__ u64 s_total[4];
+    __shared__ u32 s_total_flag[4];
+    __shared__ u32 s_scanned; // tiles the scan wave has consumed (flow control of the 4-deep hand-off ring)
+    __shared__ u32 s_arrival;
+
+    const u32 lane = lane_id();
+    const u32 wave = wave_id();
+    const bool worker = wave < (u32)kSumWorkers;
+
+    if (threadIdx.x < 4) {
+        s_arrived[threadIdx.x] = 0;
+        s_total_flag[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) {
+        s_scanned = 0;
+        s_arrival = draw_arrival(a.ctrl);
+    }
+    __syncthreads();
+    const u32 arrival = uniform32(s_arrival);
+    if (a.census) {
+        if (threadIdx.x == 0) { // residency census, see compress_kernel
+            const u64 t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < 3000) __builtin_amdgcn_s_sleep(8);
+            if (arrival == 0)
+                a.ctrl[kCtlCensus] = __hip_atomic_load(a.ctrl + kCtlStart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        return;
+    }
+    const u32 stride = gridDim.x;
+    const u32 row_stride = (stride + 3u) & ~3u;
+    const u32 n_tiles = (u32)a.n_tiles;                                      // expand tiles (4096 words)
+    const u32 n_wg_tiles = (n_tiles + (u32)kSumWorkers - 1u) / (u32)kSumWorkers; // workgroup tiles
+
+    if (!worker) {
+        // scan wave: workgroup-tile totals -> exclusive bases; then the bases of the expand tiles inside
+        GenScan scan = {0, 0, 0};
+        u64 own_prev = 0, below_prev = 0;
+        u32 gen = 0;
+        for (u32 wt = arrival; wt < n_wg_tiles; wt += stride, ++gen) {
+            const u32 q = gen & 3u;
+            if (!lds_wait(&s_total_flag[q], gen + 1u, a.ctrl, lane)) break;
+            const u64 total = uniform64(lds_ld64(&s_total[q]));
+            const u64 part = lane < (u32)kSumWorkers ? lds_ld64(&s_part[q][lane]) : 0ull;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) lds_st(&s_scanned, gen + 1u); // the ring slot may be reused
+            const u64 excl = resolve_generation64(a.gen_desc, a.big, gen, arrival, stride, row_stride, total, scan, own_prev,
+                                                  below_prev, lane, a.ctrl);
+            // lane w: groups in front of expand tile wt * kSumWorkers + w
+            const u64 incl_part = wave_scan_incl(part, lane);
+            const u32 et = wt * (u32)kSumWorkers + lane;
+            if (lane < (u32)kSumWorkers && et < n_tiles) a.tile_base[et] = excl + (incl_part - part);
+            if (lane == 0 && wt == n_wg_tiles - 1) {
+                const u64 groups = excl + total;
+                a.tile_base[n_tiles] = groups;
+                a.info[1] = groups;
+                a.info[0] = (31ull * groups + 31ull) / 32ull; // decompress.cu:84-93
+            }
+        }
+        return;
+    }
+
+    // worker waves: stream one expand tile per iteration, sum the group counts (getCounts, kernels.cu:291-309)
+    uint4 pre[4];
+    // A fill word of count 0 expands to nothing; the reference decoder steps over it (kernels.cu:332-354).  The
+    // expand kernel's rank arithmetic assumes that every word owns at least one group, so every tile is checked here
+    // and expand takes its index-map route for the tiles concerned (tile_flags).  `pre_whole`: the prefetched round
+    // consists of real words only (no padding past the end, which is written as empty fills); `pre_empty`: a round
+    // that needed bounds checks contains an empty fill among its real words.
+    bool pre_empty = false, pre_whole = true;
+    // round `rd` (0..3) of expand tile `et`: 1024 words as four fully coalesced 1 KiB loads (order is irrelevant)
+    auto load_round = [&](u32 et, u32 rd) {
+        const u64 w0 = (u64)et * kScanTileWords + (u64)rd * 1024u;
+        if (a.aligned16 && w0 + 1024u <= a.c_words) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.comp + w0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pre[k] = src[k * 64 + (int)lane];
+            pre_whole = true;
+            pre_empty = false;
+        } else {
+            u32 t[16];
+            pre_whole = false;
+            pre_empty = false;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const u64 i = w0 + (u64)(k / 4) * 256u + (u64)lane * 4u + (u64)(k % 4);
+                t[k] = i < a.c_words ? a.comp[i] : 0x80000000u; // past the end: a fill of zero groups
+                pre_empty |= i < a.c_words && word_groups(t[k]) == 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pre[k] = make_uint4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
+        }
+    };
+    if (arrival < n_wg_tiles) load_round(arrival * (u32)kSumWorkers + wave, 0);
+    u32 gen = 0;
+    for (u32 wt = arrival; wt < n_wg_tiles; wt += stride, ++gen) {
+        const u32 et = wt * (u32)kSumWorkers + wave;
+        u64 mine = 0;
+        bool tile_empty = false;
+#pragma unroll
+        for (u32 rd = 0; rd < 4; ++rd) {
+            uint4 cur[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[k] = pre[k];
+            const bool cur_whole = pre_whole;
+            tile_empty |= pre_empty;
+            // rolling prefetch: next round of this tile, or round 0 of this wave's next tile
+            if (rd < 3)
+                load_round(et, rd + 1);
+            else if (wt + stride < n_wg_tiles)
+                load_round((wt + stride) * (u32)kSumWorkers + wave, 0);
+            u32 round_min = 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { // four counts of < 2^30 each fit 32 bits; words past the end are empty fills
+                const u32 nx = word_groups(cur[k].x), ny = word_groups(cur[k].y), nz = word_groups(cur[k].z), nw = word_groups(cur[k].w);
+                mine += (u64)(nx + ny + nz + nw);
+                round_min = min(min(round_min, min(nx, ny)), min(nz, nw));
+            }
+            if (cur_whole) tile_empty |= round_min == 0u;
+        }
+        {
+            const bool any_empty = __any(tile_empty);
+            if (lane == 0 && (u64)et < a.n_tiles) a.tile_flags[et] = any_empty ? 1 : 0;
+        }
+        const u64 wave_total = uniform64(wave_sum(mine));
+        const u32 q = gen & 3u;
+        u32 last = 0;
+        if (lane == 0) {
+            // the ring slot is free once the scan wave has consumed the tile that used it 4 generations ago
+            if (gen >= 4) lds_wait_reached(&s_scanned, gen - 3u, a.ctrl);
+            __hip_atomic_store((lds_u64_ptr)&s_part[q][wave], wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            last = __hip_atomic_fetch_add((lds_u32_ptr)&s_arrived[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ==
+                   (u32)kSumWorkers - 1u;
+        }
+        if (uniform32(last)) {
+            if (lane == 0) {
+                u64 total = 0;
+#pragma unroll
+                for (int w = 0; w < kSumWorkers; ++w) total += lds_ld64(&s_part[q][w]);
+                // publish: one 4-byte granule; totals of 2^31 - 1 groups or more go through the 64-bit side entry
+                if (total >= kGenEscape) {
+                    __hip_atomic_store(a.big + ((u64)gen * stride + arrival), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    publish_generation(a.gen_desc, gen, arrival, row_stride, kGenEscape);
+                } else {
+                    publish_generation(a.gen_desc, gen, arrival, row_stride, (u32)total);
+                }
+                lds_st(&s_arrived[q], 0u);
+                __hip_atomic_store((lds_u64_ptr)&s_total[q], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                lds_publish(&s_total_flag[q], gen + 1u);
+            }
+        }
+    }
+}
+
+// word `idx` (tile-local index) of the stream: LDS inside the tile, global memory past its end
+__device__ __forceinline__ u32 tile_word(const u32 *s_words, const ExpandArgs &a, u64 tile_w0, u32 idx) {
+    if (idx < (u32)kScanTileWords) return s_words[idx];
+    const u64 g = tile_w0 + idx;
+    return g < a.c_words ? a.comp[g] : 0u;
+}
+
+// Flags of one output segment: the byte for group p lives at (p % 64) * 16 + p / 64, so that ONE 16-byte LDS read
+// hands a lane the flags of its group in all 16 steps.  Behind the 1024 flags a dump area takes the stores of lanes
+// that have nothing to flag (cheaper than masking them off).
+constexpr u32 kFlagBytes = kSegGroups + 64;
+__device__ __forceinline__ u32 flag_slot(u32 p) { return ((p & 63u) << 4) | (p >> 6); }
+
+// The 16 steps of one output segment: 64 groups -> 62 output words each.  kWhole: all 1024 groups exist and the
+// whole segment lies inside the output; kLocal: every source word is inside the LDS-resident tile.  (Template
+// parameters so that the step body is straight-line code.)
+template <bool kWhole, bool kLocal>
+__device__ __forceinline__ void expand_steps(const ExpandArgs &a, const u32 *s_words, const unsigned char *flag, u64 tile_w0,
+                                             __amdgpu_buffer_rsrc_t rsrc, u32 first_word, u32 nvalid, u32 lane) {
+    // 31 -> 32 repack (mergeWords, kernels.cu:375): output word 62 s + l takes stream bits [32 (62 s + l), +32) =
+    // groups 64 s + l + (l >= 31) and the next one, shifted by l mod 31.  Lane L decodes group 64 s + L; lanes 0..30
+    // build words 0..30 and lanes 32..62 words 31..61 from their own group and the neighbour's (one DPP shift),
+    // lanes 31 and 63 only lend their group.
+    const u32 o = lane & 31u;
+    const u32 up = 31u - ((lane - 1u) & 31u);             // what my group is shifted up by in my LEFT neighbour's word
+    const u32 soff = o != 31u ? (lane - (lane >> 5)) * 4u : 0xFFFFF000u; // lanes 31, 63: out of range, dropped
+    const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
+    const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
+    u32 before4 = (first_word - 1u) * 4u;                 // byte offset of (first_word + flags in earlier steps - 1)
+#pragma unroll
+    for (int s = 0; s < (int)kSteps; ++s) {
+        const u32 fb = (f[s >> 2] >> (8 * (s & 3))) & 0xFFu;  // 1: a word starts at my group
+        const u64 m = __ballot(fb != 0u);
+        // inclusive rank among this step's flags (the count is seeded with my own flag), plus all earlier ones
+        const u32 r4 = (__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, fb)) << 2) + before4;
+        before4 = (u32)__builtin_amdgcn_readlane((int)r4, 63); // the last lane's rank counts every flag so far
+        const u32 src_word = kLocal ? *reinterpret_cast<const u32 *>(reinterpret_cast<const unsigned char *>(s_words) + r4)
+                                    : tile_word(s_words, a, tile_w0, r4 >> 2);
+        // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354)
+        const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
+        u32 grp = (int)src_word < 0 ? fill_val : src_word;
+        if (!kWhole && (u32)(64 * s) + lane >= nvalid) grp = 0u;
+        const u32 hi_part = (u32)__builtin_amdgcn_mov_dpp((int)(grp << up), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+        const u32 word = (grp >> o) | hi_part;
+        __builtin_amdgcn_raw_buffer_store_b32(word, rsrc, soff + 248u * s, 0, 0);
+    }
+}
+
+// flags are in place: expand the segment
+__device__ __forceinline__ void expand_emit(const ExpandArgs &a, const u32 *s_words, const unsigned char *flag, u64 tile_w0,
+                                            u32 first_word, u32 nvalid, u64 out_words, u64 seg, bool local, u32 lane) {
+    const bool whole = nvalid == kSegGroups && (seg + 1) * kSegWords <= out_words;   // wave-uniform
+    const u64 seg_w0 = seg * kSegWords;
+    const u32 seg_words = whole ? kSegWords : (out_words > seg_w0 ? (u32)(out_words - seg_w0 < kSegWords ? out_words - seg_w0 : kSegWords) : 0u);
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + seg_w0, seg_words * 4u); // stores past the end are dropped
+    if (whole) {
+        if (local)
+            expand_steps<true, true>(a, s_words, flag, tile_w0, rsrc, first_word, nvalid, lane);
+        else
+            expand_steps<true, false>(a, s_words, flag, tile_w0, rsrc, first_word, nvalid, lane);
+    } else {
+        expand_steps<false, false>(a, s_words, flag, tile_w0, rsrc, first_word, nvalid, lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// ---- one output segment, general version: any counts, 64-bit positions (foreign streams with giant fills) ---------
+__device__ __forceinline__ void expand_segment_general(const ExpandArgs &a, const u32 *s_words, const u64 *s_coarse,
+                                                       unsigned char *flag, u64 tile_w0, u64 base, u64 groups,
+                                                       u64 out_words, u64 seg, u32 lane) {
+    const u64 target = seg * kSegGroups - base; // tile-relative position of the segment's first group
+    const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
+    // 64-ary search over the coarse prefix: last 64-word bucket that starts at or before the target
+    const u64 c = lane < kCoarse ? s_coarse[lane] : ~0ull;
+    const u32 bucket = (u32)__popcll(__ballot(c <= target)) - 1u;
+    const u64 drop = target - uniform64(s_coarse[bucket]); // groups of the bucket in front of the segment
+
+    reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // mark the first group of every word that contributes to the segment (clipped at the segment start)
+    u32 first_word = 0; // tile-local index of the word that covers the segment's first group
+    bool have_first = false;
+    u64 seen = 0;       // groups of the words looked at so far, from the bucket start
+    u32 wi = bucket * 64u;
+    while (seen < drop + nvalid && tile_w0 + wi < a.c_words) {
+        const u32 idx = wi + lane;
+        const bool in = tile_w0 + idx < a.c_words;
+        const u32 ww = in ? tile_word(s_words, a, tile_w0, idx) : 0u;
+        const u32 n = in ? word_groups(ww) : 0u;
+        bool contributes;
+        u32 p = 0;
+        u64 batch_total;
+        if (__ballot(n > (1u << 20)) == 0 && drop - (seen < drop ? seen : drop) < (1ull << 27)) {
+            // common case: everything fits 32 bits relative to `seen`
+            const u32 incl_n = wave_scan_incl32(n);
+            const u32 lead = (u32)(drop - (seen < drop ? seen : drop)); // groups still to drop in this batch
+            const u32 past = seen > drop ? (u32)(seen - drop) : 0u;     // segment groups already covered
+            const u32 lo = incl_n - n, hi = incl_n;
+            contributes = n != 0 && hi > lead && lo + past < lead + nvalid;
+            p = (lo > lead ? lo - lead : 0u) + past;
+            batch_total = (u32)__builtin_amdgcn_readlane((int)incl_n, 63);
+        } else {
+            const u64 incl_n = wave_scan_incl((u64)n, lane);
+            const u64 lo = seen + (incl_n - n), hi = seen + incl_n; // the word covers [lo, hi) from the bucket start
+            contributes = n != 0 && hi > drop && lo < drop + nvalid;
+            p = lo > drop ? (u32)(lo - drop) : 0u;
+            batch_total = uniform64(__shfl(incl_n, 63));
+        }
+        if (contributes) flag[flag_slot(p)] = 1; // distinct groups: plain byte stores, no atomics
+        const u64 cmask = __ballot(contributes);
+        if (!have_first && cmask) {
+            first_word = uniform32(wi + (u32)__ffsll((long long)cmask) - 1u);
+            have_first = true;
+        }
+        seen += batch_total;
+        wi += 64u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (seen < drop + nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
+        if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+        return;
+    }
+    expand_emit(a, s_words, flag, tile_w0, first_word, nvalid, out_words, seg, false, lane);
+}
+
+// ---- one output segment, streams with fill words of count 0 (foreign streams only; the reference decoder steps over
+// such words, kernels.cu:332-354).  The rank arithmetic of the routines above assumes that consecutive contributing
+// words are consecutive in the stream, which an empty word in between breaks.  Here every contributing word writes
+// its own index at the group it starts at, and a group's source is the last index written at or before it (a
+// running maximum: indices grow with position).  One wavefront, 4 KiB of LDS (`src`), any counts. ----------------
+__device__ __forceinline__ void expand_segment_with_empties(const ExpandArgs &a, const u32 *s_words, const u64 *s_coarse,
+                                                            u32 *src, u64 tile_w0, u64 base, u64 groups, u64 out_words,
+                                                            u64 seg, u32 lane) {
+    const u64 target = seg * kSegGroups - base; // tile-relative position of the segment's first group
+    const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
+    const u64 c = lane < kCoarse ? s_coarse[lane] : ~0ull;
+    const u32 bucket = (u32)__popcll(__ballot(c <= target)) - 1u;
+    const u64 drop = target - uniform64(s_coarse[bucket]); // groups of the bucket in front of the segment
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<uint4 *>(src)[k * 64 + (int)lane] = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    u64 seen = 0; // groups of the words looked at so far, from the bucket start
+    u32 wi = bucket * 64u;
+    while (seen < drop + nvalid && tile_w0 + wi < a.c_words) {
+        const u32 idx = wi + lane;
+        const bool in = tile_w0 + idx < a.c_words;
+        const u32 n = in ? word_groups(tile_word(s_words, a, tile_w0, idx)) : 0u;
+        const u64 incl_n = wave_scan_incl((u64)n, lane);
+        const u64 lo = seen + (incl_n - n), hi = seen + incl_n; // the word covers [lo, hi) from the bucket start
+        if (n != 0u && hi > drop && lo < drop + nvalid) src[lo > drop ? (u32)(lo - drop) : 0u] = idx + 1u;
+        seen += uniform64(__shfl(incl_n, 63));
+        wi += 64u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (seen < drop + nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
+        if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+        return;
+    }
+    const u64 seg_w0 = seg * kSegWords;
+    const u32 seg_words = out_words > seg_w0 ? (u32)(out_words - seg_w0 < kSegWords ? out_words - seg_w0 : kSegWords) : 0u;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + seg_w0, seg_words * 4u); // stores past the end are dropped
+    const u32 o = lane & 31u;
+    const u32 up = 31u - ((lane - 1u) & 31u);
+    const u32 soff = o != 31u ? (lane - (lane >> 5)) * 4u : 0xFFFFF000u;
+    u32 carry = 0;
+    for (u32 s = 0; s < kSteps; ++s) {
+        const u32 m = max(wave_scan_max32(src[64u * s + lane]), carry); // index + 1 of the word my group belongs to
+        carry = (u32)__builtin_amdgcn_readlane((int)m, 63);
+        const u32 src_word = tile_word(s_words, a, tile_w0, m ? m - 1u : 0u);
+        const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
+        u32 grp = (int)src_word < 0 ? fill_val : src_word;
+        if (64u * s + lane >= nvalid) grp = 0u;
+        const u32 hi_part = (u32)__builtin_amdgcn_mov_dpp((int)(grp << up), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+        __builtin_amdgcn_raw_buffer_store_b32((grp >> o) | hi_part, rsrc, soff + 248u * s, 0, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// ---- one output segment, fast version: the tile expands to fewer than 2^31 groups, so every position relative to the
+// segment start fits a signed 32-bit integer; bookkeeping stays in vector registers (see compress_kernel) ----------
+
+// One batch of the mark phase: the next 128 words, two per lane.  `rel` = where the batch starts, seen from the
+// segment start (<= 0 at first).  Flags the group at which every contributing word starts (clipped at the segment
+// start).  kFirst: returns the tile-local index of the first contributing word.
+template <bool kLocal, bool kFirst>
+__device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, const u32 *s_words, unsigned char *flag, u64 tile_w0,
+                                          u32 left_in_stream, u32 nvalid, u32 lane, int &rel, u32 &wi) {
+    const u32 i0 = wi + 2u * lane;
+    u32 w0, w1;
+    if (kLocal) {
+        const uint2 q = *reinterpret_cast<const uint2 *>(s_words + i0);
+        w0 = q.x;
+        w1 = q.y;
+    } else { // past the tile: global memory; past the stream: empty fills
+        w0 = i0 < left_in_stream ? a.comp[tile_w0 + i0] : 0x80000000u;
+        w1 = i0 + 1u < left_in_stream ? a.comp[tile_w0 + i0 + 1u] : 0x80000000u;
+    }
+    const u32 n0 = word_groups(w0), n1 = word_groups(w1);
+    // all literals (dense data): consecutive positions, no scan; otherwise one DPP scan over the pair sums
+    const u32 incl = __ballot((int)(w0 | w1) < 0) == 0 ? 2u * lane + 2u : wave_scan_incl32(n0 + n1);
+    const int hi1 = rel + (int)incl, lo1 = hi1 - (int)n1, lo0 = lo1 - (int)n0; // words cover [lo0, lo1) and [lo1, hi1)
+    // clip to the segment [0, nvalid): a word contributes iff something is left of it
+    const int s0 = lo0 > 0 ? lo0 : 0, e0 = lo1 < (int)nvalid ? lo1 : (int)nvalid;
+    const int s1 = lo1 > 0 ? lo1 : 0, e1 = hi1 < (int)nvalid ? hi1 : (int)nvalid;
+    const bool c0 = e0 > s0, c1 = e1 > s1;
+    // distinct groups: plain byte stores, no atomics.  slot(p) + base = base + 16 p - 1023 (p / 64): three instructions
+    const u32 fbase = (u32)(uintptr_t)(lds_u8_ptr)flag;
+    const u32 dump = fbase + kSegGroups + lane;
+    const u32 a0 = (u32)__mul24(s0 >> 6, -1023) + (((u32)s0 << 4) + fbase);
+    const u32 a1 = (u32)__mul24(s1 >> 6, -1023) + (((u32)s1 << 4) + fbase);
+    *(lds_u8_ptr)(uintptr_t)(c0 ? a0 : dump) = 1;
+    *(lds_u8_ptr)(uintptr_t)(c1 ? a1 : dump) = 1;
+    u32 first = 0;
+    if (kFirst) {
+        const u64 m0 = __ballot(c0), m1 = __ballot(c1);
+        const u32 l = (u32)__ffsll((long long)(m0 | m1)) - 1u;
+        first = wi + 2u * l + (((m0 >> l) & 1ull) ? 0u : 1u);
+    }
+    rel += (int)(u32)__builtin_amdgcn_readlane((int)incl, 63);
+    wi += 128u;
+    return first;
+}
+
+__device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, const u32 *s_words, const u32 *s_coarse32,
+                                                    unsigned char *flag, u64 tile_w0, u32 target, u32 nvalid,
+                                                    u64 out_words, u64 seg, u32 lane) {
+    // 64-ary search over the coarse prefix: last 64-word bucket that starts at or before the target
+    const u32 c = lane <= kCoarse ? s_coarse32[lane] : 0xFFFFFFFFu;
+    const u32 bucket = (u32)__popcll(__ballot(lane < kCoarse && c <= target)) - 1u;
+    int rel = (int)(uniform32(s_coarse32[bucket]) - target); // <= 0: where the bucket starts, seen from the segment
+
+    reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    const u32 left_in_stream = a.c_words - tile_w0 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(a.c_words - tile_w0);
+    u32 wi = bucket * 64u;
+    constexpr u32 kLastLocal = (u32)kScanTileWords - 128u; // batches starting up to here come out of the LDS tile
+    // the word that covers the segment's first group is in the first batch (that is how the bucket was chosen)
+    const u32 first_word = wi <= kLastLocal ? mark_pairs<true, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi)
+                                            : mark_pairs<false, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi);
+    while (rel < (int)nvalid && wi <= kLastLocal)
+        (void)mark_pairs<true, false>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi);
+    while (rel < (int)nvalid && wi < left_in_stream)
+        (void)mark_pairs<false, false>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (rel < (int)nvalid) { // the stream ended inside the segment: cannot happen for a consistent scan
+        if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+        return;
+    }
+    // group g belongs to the r-th contributing word, r = (flags at positions <= g) - 1
+    expand_emit(a, s_words, flag, tile_w0, first_word, nvalid, out_words, seg, wi <= (u32)kScanTileWords, lane);
+}
+
+__global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const ExpandArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 s_words[kScanTileWords];
+    __shared__ u64 s_coarse[kCoarse + 1]; // groups in front of word 64 c, relative to the tile start
+    __shared__ u32 s_coarse32[kCoarse + 1]; // the same in 32 bits (valid when the tile total is below 2^31)
+    __shared__ u64 s_wave_sum[kExpandWaves];
+    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][kFlagBytes]; // 1: a word starts at this group
+
+    const u32 lane = lane_id();
+    const u32 wave = wave_id();
+    // a stream of few tiles (highly compressed data) expands to many segments per tile: `parts` workgroups share a tile
+    const u32 tile = blockIdx.x / a.parts;
+    const u32 part = blockIdx.x % a.parts;
+    const u64 tile_w0 = (u64)tile * kScanTileWords;
+    const u64 groups = a.info[1];
+    const u64 out_words = a.info[0];
+    // (asked for up front, used after the prologue: this tile or the next one contains fill words of count 0)
+    const u64 all_tiles = (a.c_words + kScanTileWords - 1) / kScanTileWords;
+    const bool has_empties = (a.tile_flags[tile] | ((u64)tile + 1 < all_tiles ? a.tile_flags[tile + 1] : 0)) != 0;
+    if (out_words > a.out_capacity) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+        return;
+    }
+
+    // ---- stage the tile and build the coarse prefix of group counts --------------------------------------------
+    constexpr int kVec = kExpandWordsPerThread / 4;
+    if (a.aligned16 && tile_w0 + kScanTileWords <= a.c_words) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(a.comp + tile_w0);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_words);
+        uint4 v[kVec];
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) v[k] = src[k * kExpandThreads + (int)threadIdx.x]; // coalesced 16-byte loads
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) dst[k * kExpandThreads + (int)threadIdx.x] = v[k];
+    } else {
+        for (u32 i = threadIdx.x; i < (u32)kScanTileWords; i += kExpandThreads)
+            s_words[i] = tile_w0 + i < a.c_words ? a.comp[tile_w0 + i] : 0x80000000u; // past the end: empty fill
+    }
+    __syncthreads();
+    // every thread sums the counts of its own 16 consecutive words
+    u64 mine = 0;
+    {
+        const uint4 *my = reinterpret_cast<const uint4 *>(s_words + threadIdx.x * kExpandWordsPerThread);
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) {
+            const uint4 q = my[k];
+            mine += (u64)(word_groups(q.x) + word_groups(q.y) + word_groups(q.z) + word_groups(q.w));
+        }
+    }
+    const u64 incl = wave_scan_incl(mine, lane);
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    u64 excl = incl - mine;
+    for (u32 k = 0; k < wave; ++k) excl += s_wave_sum[k];
+    constexpr u32 kThreadsPer64 = 64 / kExpandWordsPerThread;
+    if (threadIdx.x % kThreadsPer64 == 0) { // first thread of each 64 words
+        s_coarse[threadIdx.x / kThreadsPer64] = excl;
+        s_coarse32[threadIdx.x / kThreadsPer64] = (u32)excl;
+    }
+    if (threadIdx.x == kExpandThreads - 1) {
+        s_coarse[kCoarse] = excl + mine;
+        s_coarse32[kCoarse] = (u32)(excl + mine);
+    }
+    __syncthreads();
+
+    // ---- segments owned by this tile: those whose first group lies in [base, base + total) ----------------------
+    const u64 base = a.tile_base[tile];
+    const u64 total = uniform64(s_coarse[kCoarse]);
+    const u64 n_seg = (groups + kSegGroups - 1) / kSegGroups;
+    const u64 k_begin = (base + kSegGroups - 1) / kSegGroups;
+    u64 k_end = (base + total + kSegGroups - 1) / kSegGroups;
+    if (k_end > n_seg) k_end = n_seg;
+
+    if (has_empties) {
+        // this tile, or the next one (a segment reads at most 1024 + 128 words past its tile), contains fill words of
+        // count 0 (found by the sums pass): index-map route, one wavefront per workgroup, the four flag areas together
+        // hold its 1024-entry index map
+        static_assert(sizeof(s_flag) >= kSegGroups * sizeof(u32), "index map must fit the flag areas");
+        if (wave == 0)
+            for (u64 seg = k_begin + part; seg < k_end; seg += a.parts)
+                expand_segment_with_empties(a, s_words, s_coarse, reinterpret_cast<u32 *>(&s_flag[0][0]), tile_w0, base, groups,
+                                            out_words, seg, lane);
+        return;
+    }
+    unsigned char *flag = s_flag[wave];
+    const bool tame = total < (1ull << 31); // wave-uniform: positions inside this tile fit 32 bits
+    for (u64 seg = k_begin + wave + (u64)kExpandWaves * part; seg < k_end; seg += (u64)kExpandWaves * a.parts) {
+        if (tame) {
+            const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
+            expand_segment_tame(a, s_words, s_coarse32, flag, tile_w0, (u32)(seg * kSegGroups - base), nvalid, out_words, seg, lane);
+        } else {
+            expand_segment_general(a, s_words, s_coarse, flag, tile_w0, base, groups, out_words, seg, lane);
+        }
+    }
+}
+
+} // namespace
+
+int decode_sums_grid(u32 *d_ctrl, hipStream_t s) {
+    static int cached[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] > 0) return cached[dev];
+    const int upper = persistent_grid(reinterpret_cast<const void *>(&decode_sums_kernel), (kSumWorkers + 1) * 64, ~0ull);
+    ScanArgs a = {};
+    a.ctrl = d_ctrl;
+    a.census = 1;
+    int resident = 0;
+    if (launch_clear(d_ctrl, kCtlWords * sizeof(u32), s) == hipSuccess) {
+        hipLaunchKernelGGL(decode_sums_kernel, dim3(upper), dim3((kSumWorkers + 1) * 64), 0, s, a);
+        u32 seen = 0;
+        if (hipGetLastError() == hipSuccess &&
+            hipMemcpyAsync(&seen, d_ctrl + kCtlCensus, sizeof seen, hipMemcpyDeviceToHost, s) == hipSuccess &&
+            hipStreamSynchronize(s) == hipSuccess)
+            resident = (int)seen;
+    }
+    if (resident < 1) return -1;
+    if (resident > upper) resident = upper;
+    resident = whole_per_cu(resident);
+    cached[dev] = resident;
+    return resident;
+}
+
+hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(decode_sums_kernel, dim3(grid), dim3((kSumWorkers + 1) * 64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s) {
+    if (n_tiles == 0) return hipSuccess;
+    // One workgroup per tile fills the chip when the stream is long.  A short stream that expands a lot (highly
+    // compressed bitmaps: thousands of output segments per tile) is shared out: `parts` workgroups per tile, each
+    // taking every parts-th group of kExpandWaves segments.  The true output size is only known on the device; the
+    // capacity bounds it, and a part with nothing to do costs one 16 KiB tile read.
+    ExpandArgs a = a0;
+    const u64 want = 4096; // workgroups: 256 CUs x 7 resident x ~2
+    const u64 segs_per_tile = a.out_capacity / kSegWords / n_tiles;
+    u64 parts = (want + n_tiles - 1) / n_tiles;
+    if (parts > segs_per_tile / (2 * kExpandWaves)) parts = segs_per_tile / (2 * kExpandWaves);
+    if (parts < 1) parts = 1;
+    if (parts > 1024) parts = 1024;
+    a.parts = (u32)parts;
+    hipLaunchKernelGGL(decode_expand_kernel, dim3((unsigned)(n_tiles * parts)), dim3(kExpandThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace wah

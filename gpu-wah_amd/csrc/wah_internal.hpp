@@ -93,7 +93,7 @@ struct PairCheck {
     uint64_t groups;                 // what both must have expanded to
 };
 
-// launchers (wah_kernels.hip)
+// launchers (wah_compress.hip, wah_decode.hip, wah_aux.hip)
 hipError_t launch_compress(int workers, const CompressArgs &a, int grid, hipStream_t s);
 hipError_t launch_compress_pair(const CompressArgs &a, int grid, hipStream_t s);
 hipError_t launch_bitop_check(const uint64_t *info_a, const uint64_t *info_b, const uint32_t *ctrl_a, const uint32_t *ctrl_b, uint64_t groups,

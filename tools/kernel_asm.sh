@@ -2,7 +2,8 @@
 # Split the device assembly of `make -C gpu-wah_amd asm` into one file per kernel (build/<name>.s).
 set -e
 cd "$(dirname "$0")/../gpu-wah_amd"
-S=build/wah_kernels-hip-amdgcn-amd-amdhsa-gfx950.s
+cat build/wah_compress-hip-amdgcn-amd-amdhsa-gfx950.s build/wah_decode-hip-amdgcn-amd-amdhsa-gfx950.s build/wah_aux-hip-amdgcn-amd-amdhsa-gfx950.s > build/all_kernels.s
+S=build/all_kernels.s
 for k in compress_kernelILi15E compress_kernelILi7E decode_sums_kernel decode_expand_kernel; do
   sym=$(grep -o "^_ZN[A-Za-z0-9_]*${k}[A-Za-z0-9_]*:" $S | head -1 | tr -d ':')
   [ -n "$sym" ] || continue
