@@ -27,6 +27,7 @@ from .api import (  # noqa: F401
     build,
     compress,
     decompress,
+    host_cache_release,
     max_compressed_words,
     decoded_words,
     compress_device,

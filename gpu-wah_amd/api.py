@@ -8,6 +8,7 @@ import collections
 import ctypes
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -30,6 +31,7 @@ ABI_SYMBOLS = {
     "wah_compress": (_vp, [_vp, _u64, _u64p, _f32p, _f32p, _f32p]),
     "wah_decompress": (_vp, [_vp, _u64, _u64p, _f32p, _f32p, _f32p]),
     "wah_free": (None, [_vp]),
+    "wah_host_cache_release": (None, []),
     "wah_max_compressed_words": (_u64, [_u64]),
     "wah_decoded_words": (_u64, [_u64]),
     "wah_compress_workspace_bytes": (_sz, [_u64]),
@@ -140,11 +142,13 @@ def _host_call(fn, data):
              ctypes.byref(t[2]))
     if not ptr:
         raise WahError(f"{fn.__name__} returned NULL: {_err()}")
-    try:
-        out = np.ctypeslib.as_array(ctypes.cast(ptr, _u32p), shape=(max(n_out.value, 1),))[: n_out.value].copy()
-    finally:
+    if n_out.value == 0:
         lib().wah_free(ptr)
-    return out, Timings(*(x.value for x in t))
+        return np.empty(0, dtype=np.uint32), Timings(*(x.value for x in t))
+    # hand the library's buffer out as it is (no second copy of up to a bitmap); freed when the array goes away
+    buf = (ctypes.c_uint32 * n_out.value).from_address(ptr)
+    weakref.finalize(buf, lib().wah_free, ptr)
+    return np.frombuffer(buf, dtype=np.uint32), Timings(*(x.value for x in t))
 
 
 def compress(data, with_timings=False):
@@ -162,6 +166,11 @@ def decompress(comp, with_timings=False):
 # --------------------------------------------------------------------------
 # device-pointer operators (torch tensors as device memory; int32 storage)
 # --------------------------------------------------------------------------
+def host_cache_release():
+    """Return the device buffers compress()/decompress() keep between calls (include/wah.h: wah_host_cache_release)."""
+    lib().wah_host_cache_release()
+
+
 def _torch():
     import torch
 

@@ -6,6 +6,13 @@
 // memset(control block) + kernel(s) with no allocation, no blocking 8-byte
 // read-back in the middle and no library scan.
 #include <cstdio>
+#include <algorithm>
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include <sys/mman.h>
 #include <cstdlib>
 #include <cstring>
 
@@ -94,11 +101,42 @@ int read_status(void *d_workspace, void *stream, const uint64_t *d_vals = nullpt
     return WAH_OK;
 }
 
-// RAII bundle for the host-pointer paths: frees whatever was allocated, like the error
-// exits of compress.cu:89-114, and owns the timing events.
+// Device buffers of the host-pointer entry points.  The reference allocates and frees them inside every call
+// (compress.cu:57-114,177-202; decompress.cu:34-54,124-131), which puts hipMalloc/hipFree of up to two bitmap-sized
+// buffers -- milliseconds, and cold address translations for the kernels that follow -- into the timings it
+// reports.  Here the buffers are kept between calls: grow-only, one set per process, the call holds the set's
+// mutex.  wah_host_cache_release() frees them; WAH_HOST_CACHE=0 in the environment restores allocate-and-free.
+struct HostCache {
+    static constexpr int kSlots = 6;
+    std::mutex m;
+    void *buf[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t cap[kSlots] = {0, 0, 0, 0, 0, 0};
+    void release_locked() {
+        for (int i = 0; i < kSlots; ++i) {
+            if (buf[i]) (void)hipFree(buf[i]);
+            buf[i] = nullptr;
+            cap[i] = 0;
+        }
+    }
+};
+HostCache &host_cache() {
+    static HostCache *c = new HostCache; // never destroyed: the HIP runtime may be gone before static destructors run
+    return *c;
+}
+bool host_cache_enabled() {
+    static const bool on = [] {
+        const char *e = std::getenv("WAH_HOST_CACHE");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// RAII bundle for the host-pointer paths: owns the timing events and the call's claim on the buffer set
+// (or, without the cache, frees whatever was allocated, like the error exits of compress.cu:89-114).
 struct HostCall {
-    void *bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int nbufs = 0;
+    HostCache &cache = host_cache();
+    std::unique_lock<std::mutex> lock{cache.m};
+    const bool keep = host_cache_enabled();
     hipEvent_t ev[2] = {nullptr, nullptr};
     ~HostCall() {
         release();
@@ -106,18 +144,26 @@ struct HostCall {
             if (e) (void)hipEventDestroy(e);
     }
     void release() {
-        for (int i = 0; i < nbufs; ++i)
-            if (bufs[i]) (void)hipFree(bufs[i]);
-        nbufs = 0;
+        if (!keep) cache.release_locked();
     }
-    bool alloc(void **p, size_t bytes, const char *what) {
-        hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    // slot: which buffer of the set; a kept buffer that is large enough is handed out again as it is
+    bool alloc(int slot, void **p, size_t bytes, const char *what) {
+        if (bytes == 0) bytes = 16;
+        if (cache.buf[slot] && cache.cap[slot] >= bytes) {
+            *p = cache.buf[slot];
+            return true;
+        }
+        if (cache.buf[slot]) (void)hipFree(cache.buf[slot]);
+        cache.buf[slot] = nullptr;
+        cache.cap[slot] = 0;
+        hipError_t e = hipMalloc(p, bytes);
         if (e != hipSuccess) {
             set_err(what, e);
             std::fprintf(stderr, "wah: could not allocate %s (%zu bytes): %s\n", what, bytes, hipGetErrorString(e));
             return false;
         }
-        bufs[nbufs++] = *p;
+        cache.buf[slot] = *p;
+        cache.cap[slot] = bytes;
         return true;
     }
     bool init() {
@@ -133,11 +179,78 @@ struct HostCall {
     }
 };
 
+// Result buffers of the host-pointer paths: free()-compatible like the reference's malloc (compress.cu:177,
+// decompress.cu:127), but large ones are 2 MiB aligned and marked for transparent huge pages -- the copy back from the
+// device is the first touch of this memory, and with 4 KiB pages its page faults, not PCIe, set the pace.
+// *huge: the buffer is backed by huge pages on first touch (what copy_to_fresh_host() needs to know).
+bool thp_available() {
+    static const bool on = [] {
+        char line[128] = "";
+        if (FILE *f = std::fopen("/sys/kernel/mm/transparent_hugepage/enabled", "r")) {
+            if (!std::fgets(line, sizeof line, f)) line[0] = 0;
+            std::fclose(f);
+        }
+        return line[0] != 0 && std::strstr(line, "[never]") == nullptr;
+    }();
+    return on;
+}
+void *host_result_alloc(size_t bytes, bool *huge) {
+    constexpr size_t kHuge = size_t(2) << 20;
+    *huge = false;
+    if (bytes >= 2 * kHuge && thp_available()) {
+        const size_t rounded = (bytes + kHuge - 1) & ~(kHuge - 1);
+        void *p = std::aligned_alloc(kHuge, rounded);
+        if (p) {
+            *huge = madvise(p, rounded, MADV_HUGEPAGE) == 0;
+            return p;
+        }
+    }
+    return std::malloc(bytes ? bytes : sizeof(uint32_t));
+}
+
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
     set_err(what, e);
     std::fprintf(stderr, "wah: %s failed: %s\n", what, hipGetErrorString(e));
     return false;
+}
+
+// Device -> fresh host buffer.  Measured on the box (tools/scratch/d2h_probe.hip, 1 GiB): hipMemcpy into memory that
+// has been touched runs at 56 GB/s, into untouched memory at 17-21 GB/s, because the copy takes the page faults one at
+// a time.  With huge pages four threads fault 1 GiB in within 11 ms, so they run ahead of the copy, chunk by chunk, and
+// the whole transfer reaches 47 GB/s.  (With 4 KiB pages concurrent faults contend and the plain copy is the faster
+// one; MADV_POPULATE_WRITE does not scale over threads either.)
+bool copy_to_fresh_host(void *host, const void *dev, size_t bytes, bool huge, const char *what) {
+    constexpr size_t kChunk = size_t(16) << 20;
+    const size_t n_chunks = (bytes + kChunk - 1) / kChunk;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_threads = hw >= 8 ? 4 : hw >= 4 ? 2 : 1;
+    if (!huge || n_chunks < 2) return hip_ok(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost), what);
+
+    std::unique_ptr<std::atomic<uint8_t>[]> ready(new std::atomic<uint8_t>[n_chunks]);
+    for (size_t i = 0; i < n_chunks; ++i) ready[i].store(0, std::memory_order_relaxed);
+    std::atomic<bool> stop{false};
+    auto fault_in = [&](unsigned t) {
+        for (size_t i = t; i < n_chunks && !stop.load(std::memory_order_relaxed); i += n_threads) {
+            volatile char *p = static_cast<char *>(host) + i * kChunk;
+            const size_t len = std::min(kChunk, bytes - i * kChunk);
+            for (size_t o = 0; o < len; o += 4096) p[o] = 0;
+            ready[i].store(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> helpers;
+    helpers.reserve(n_threads);
+    for (unsigned t = 0; t < n_threads; ++t) helpers.emplace_back(fault_in, t);
+    bool ok = true;
+    for (size_t i = 0; i < n_chunks && ok; ++i) {
+        while (!ready[i].load(std::memory_order_acquire)) std::this_thread::yield();
+        const size_t len = std::min(kChunk, bytes - i * kChunk);
+        ok = hip_ok(hipMemcpy(static_cast<char *>(host) + i * kChunk, static_cast<const char *>(dev) + i * kChunk, len,
+                              hipMemcpyDeviceToHost), what);
+    }
+    stop.store(true, std::memory_order_relaxed);
+    for (std::thread &h : helpers) h.join();
+    return ok;
 }
 
 } // namespace
@@ -155,6 +268,11 @@ extern "C" {
 const char *wah_last_error(void) { return g_err; }
 const char *wah_version(void) { return "wah-mi355x 0.1 gfx950"; }
 void wah_free(void *p) { std::free(p); }
+void wah_host_cache_release(void) {
+    HostCache &c = host_cache();
+    std::lock_guard<std::mutex> g(c.m);
+    c.release_locked();
+}
 
 uint64_t wah_max_compressed_words(uint64_t n_words) { return (32u * n_words + 30u) / 31u; }
 uint64_t wah_decoded_words(uint64_t n_groups) { return (31u * n_groups + 31u) / 32u; }
@@ -558,10 +676,10 @@ uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *ou
     const uint64_t cap = wah_max_compressed_words(n_words);
     const size_t ws_bytes = wah_compress_workspace_bytes(n_words);
     void *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr, *d_cnt = nullptr;
-    if (!hc.alloc(&d_in, n_words * sizeof(uint32_t), "space for the data")) return nullptr;
-    if (!hc.alloc(&d_out, cap * sizeof(uint32_t), "space for the compressed output")) return nullptr;
-    if (!hc.alloc(&d_ws, ws_bytes, "workspace")) return nullptr;
-    if (!hc.alloc(&d_cnt, sizeof(uint64_t), "output size")) return nullptr;
+    if (!hc.alloc(0, &d_in, n_words * sizeof(uint32_t), "space for the data")) return nullptr;
+    if (!hc.alloc(1, &d_out, cap * sizeof(uint32_t), "space for the compressed output")) return nullptr;
+    if (!hc.alloc(2, &d_ws, ws_bytes, "workspace")) return nullptr;
+    if (!hc.alloc(3, &d_cnt, sizeof(uint64_t), "output size")) return nullptr;
     if (n_words && !hip_ok(hipMemcpy(d_in, data_host, n_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
         return nullptr;
     t_in = hc.stop();
@@ -580,12 +698,13 @@ uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *ou
 
     // phase 3: D2H + free (compress.cu:177-202)
     hc.start();
-    uint32_t *host = static_cast<uint32_t *>(std::malloc((c ? c : 1) * sizeof(uint32_t)));
+    bool huge = false;
+    uint32_t *host = static_cast<uint32_t *>(host_result_alloc(c * sizeof(uint32_t), &huge));
     if (!host) {
         set_err("host malloc failed");
         return nullptr;
     }
-    if (c && !hip_ok(hipMemcpy(host, d_out, c * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy final output")) {
+    if (c && !copy_to_fresh_host(host, d_out, c * sizeof(uint32_t), huge, "copy final output")) {
         std::free(host);
         return nullptr;
     }
@@ -619,9 +738,9 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     hc.start();
     void *d_comp = nullptr, *d_info = nullptr, *d_ws0 = nullptr;
     const size_t ws0 = wah_decompress_workspace_bytes(c_words, 0);
-    if (!hc.alloc(&d_comp, c_words * sizeof(uint32_t), "space for the compressed data")) return nullptr;
-    if (!hc.alloc(&d_info, 2 * sizeof(uint64_t), "output size")) return nullptr;
-    if (!hc.alloc(&d_ws0, ws0, "scan workspace")) return nullptr;
+    if (!hc.alloc(1, &d_comp, c_words * sizeof(uint32_t), "space for the compressed data")) return nullptr;
+    if (!hc.alloc(3, &d_info, 2 * sizeof(uint64_t), "output size")) return nullptr;
+    if (!hc.alloc(4, &d_ws0, ws0, "scan workspace")) return nullptr;
     if (c_words && !hip_ok(hipMemcpy(d_comp, comp_host, c_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
         return nullptr;
     t_in = hc.stop();
@@ -638,7 +757,7 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     }
     const uint64_t n_out = info[0], groups = info[1];
     void *d_out = nullptr;
-    if (!hc.alloc(&d_out, n_out * sizeof(uint32_t), "space for the result")) return nullptr;
+    if (!hc.alloc(0, &d_out, n_out * sizeof(uint32_t), "space for the result")) return nullptr;
     // the tile bases of the scan are still in the workspace: expand only
     rc = wah_decompress_expand_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(d_out), n_out,
                                       static_cast<uint64_t *>(d_info), d_ws0, ws0, nullptr);
@@ -652,12 +771,15 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     // phase 3: D2H + free (decompress.cu:124-131).  The reference hands back a buffer of G words
     // (one per group) of which ceil(31 G / 32) are meaningful; we keep the size and zero the rest.
     hc.start();
-    uint32_t *host = static_cast<uint32_t *>(std::calloc(groups ? groups : 1, sizeof(uint32_t)));
+    bool huge = false;
+    uint32_t *host = static_cast<uint32_t *>(host_result_alloc(groups * sizeof(uint32_t), &huge));
     if (!host) {
         set_err("host malloc failed");
         return nullptr;
     }
-    if (n_out && !hip_ok(hipMemcpy(host, d_out, n_out * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy final output")) {
+    if (groups > n_out) std::memset(host + n_out, 0, (groups - n_out) * sizeof(uint32_t));
+    if (groups == 0) host[0] = 0;
+    if (n_out && !copy_to_fresh_host(host, d_out, n_out * sizeof(uint32_t), huge, "copy final output")) {
         std::free(host);
         return nullptr;
     }

@@ -48,6 +48,27 @@ def test_kats_host_api(wah, kats):
         assert np.array_equal(back[: k["n_words"]], k["data"]), k["name"]
 
 
+def test_host_calls_reuse_their_device_buffers(wah, oracle):
+    """The host entry points keep their device buffers between calls (include/wah.h: wah_host_cache_release):
+    growing, shrinking and released sets all give the oracle's words, and so does WAH_HOST_CACHE=0."""
+    rng = np.random.default_rng(5)
+    sizes = [992 * 40, 17, 992 * 300 + 5, 0, 992 * 40, 2_000_000, 31]
+    cases = [(rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32) & np.uint32(0x01010000) if i % 2 else
+              rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)) for i, n in enumerate(sizes)]
+    for rnd in range(2):
+        for a in cases:
+            comp = wah.compress(a)
+            assert np.array_equal(comp, oracle.compress(a))
+            assert np.array_equal(wah.decompress(comp)[: a.size], a)
+        wah.host_cache_release()
+    code = ("import importlib, numpy as np; w = importlib.import_module('gpu-wah_amd'); "
+            "a = (np.arange(50000, dtype=np.uint32) * 2654435761 >> 7).astype(np.uint32) & 0x10001; "
+            "[np.testing.assert_array_equal(w.decompress(w.compress(a))[:a.size], a) for _ in range(3)]; print('ok')")
+    env = dict(os.environ, WAH_HOST_CACHE="0")
+    out = subprocess.run(["python3", "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-2000:]
+
+
 def test_kats_device_api(wah, kats):
     for k in kats:
         got = _host(wah.compress_device(_dev(k["data"])))
