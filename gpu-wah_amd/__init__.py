@@ -32,6 +32,7 @@ from .api import (  # noqa: F401
     decoded_words,
     compress_device,
     decompress_device,
+    decompress_segments_device,
     DeviceCompressor,
     DeviceDecompressor,
     validate_device,

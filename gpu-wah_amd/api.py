@@ -42,6 +42,8 @@ ABI_SYMBOLS = {
     "wah_decompress_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_scan_device": (_int, [_vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_expand_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_decompress_segments_workspace_bytes": (_sz, []),
+    "wah_decompress_segments_device": (ctypes.c_int, [_vp, _u64, _vp, _u64, _u64, _u64, _vp, _u64, _vp, _sz, _vp]),
     "wah_decompress_status": (_int, [_vp, _vp]),
     "wah_validate_device": (_int, [_vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_merge_fills_workspace_bytes": (_sz, [_u64]),
@@ -277,6 +279,33 @@ def decompress_device(d_comp, out_capacity_words):
     d = DeviceDecompressor(d_comp.numel(), out_capacity_words, device=d_comp.device)
     d.run(d_comp)
     return d.result().clone()
+
+
+def decompress_segments_device(d_comp, seg_offsets, n_words, first_segment=0, n_segments=None, out=None, workspace=None,
+                               check=True):
+    """Segments [first_segment, first_segment + n_segments) of the bitmap (992 words each, the last one shorter) from a
+    stream of an `indexed` compressor and its seg_offsets, without scanning the stream (wah_decompress_segments_device).
+    `out` / `workspace`: reuse these tensors; check=False: only enqueue (the caller reads the status later)."""
+    torch = _torch()
+    _as_words(torch, d_comp)
+    groups = max_compressed_words(int(n_words))
+    all_segments = (groups + 1023) // 1024
+    if n_segments is None:
+        n_segments = all_segments - first_segment
+    total = decoded_words(groups)
+    need = max(0, min((first_segment + n_segments) * 992, total) - first_segment * 992) if n_segments else 0
+    if out is None:
+        out = torch.empty(max(need, 1), dtype=torch.int32, device=d_comp.device)
+    ws_bytes = int(lib().wah_decompress_segments_workspace_bytes())
+    if workspace is None:
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=d_comp.device)
+    rc = lib().wah_decompress_segments_device(d_comp.data_ptr(), d_comp.numel(), seg_offsets.data_ptr(), int(n_words),
+                                              int(first_segment), int(n_segments), out.data_ptr(), out.numel(),
+                                              workspace.data_ptr(), workspace.numel(), _stream_ptr(torch))
+    _check(rc, "wah_decompress_segments_device")
+    if check:
+        _check(lib().wah_decompress_status(workspace.data_ptr(), _stream_ptr(torch)), "decompress_segments")
+    return out[:need]
 
 
 def merge_fills_device(d_comp):

@@ -652,6 +652,60 @@ int wah_copy_device(const uint32_t *d_in, uint32_t *d_out, uint64_t n_words, voi
     return WAH_OK;
 }
 
+size_t wah_decompress_segments_workspace_bytes(void) { return round256(wah::kCtlWords * sizeof(uint32_t)); }
+
+int wah_decompress_segments_device(const uint32_t *d_comp, uint64_t c_words, const uint64_t *d_segment_offsets, uint64_t n_words,
+                                   uint64_t first_segment, uint64_t n_segments, uint32_t *d_out, uint64_t out_capacity_words,
+                                   void *d_workspace, size_t workspace_bytes, void *stream) {
+    g_err[0] = 0;
+    if (!d_workspace || !d_segment_offsets || (c_words && !d_comp) || (n_segments && !d_out)) {
+        set_err("null pointer");
+        return WAH_ERR_ARG;
+    }
+    if (n_words >= (1ull << 40) || c_words >= (1ull << 40) || (reinterpret_cast<uintptr_t>(d_comp) & 3u) ||
+        (reinterpret_cast<uintptr_t>(d_out) & 3u) || (reinterpret_cast<uintptr_t>(d_workspace) & 255u)) {
+        set_err("size out of range or misaligned pointer");
+        return WAH_ERR_ARG;
+    }
+    if (workspace_bytes < wah_decompress_segments_workspace_bytes()) {
+        set_err("workspace too small");
+        return WAH_ERR_ARG;
+    }
+    const uint64_t groups = wah_max_compressed_words(n_words); // G = ceil(32 n / 31)
+    const uint64_t all_segments = (groups + wah::kSegGroups - 1) / wah::kSegGroups;
+    if (first_segment > all_segments || n_segments > all_segments - first_segment) {
+        set_err("segment range outside the bitmap");
+        return WAH_ERR_ARG;
+    }
+    const uint64_t out_words = wah_decoded_words(groups);
+    const uint64_t range_end = (first_segment + n_segments) * wah::kSegWords < out_words ? (first_segment + n_segments) * wah::kSegWords : out_words;
+    const uint64_t needed = n_segments ? range_end - first_segment * wah::kSegWords : 0;
+    if (needed > out_capacity_words) {
+        set_err("output capacity too small");
+        return WAH_ERR_CAPACITY;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = wah::launch_clear(d_workspace, wah::kCtlWords * sizeof(uint32_t), s);
+    if (e == hipSuccess) {
+        wah::SegmentsArgs a = {};
+        a.comp = d_comp;
+        a.c_words = c_words;
+        a.seg_offsets = d_segment_offsets;
+        a.first_segment = first_segment;
+        a.n_segments = n_segments;
+        a.groups = groups;
+        a.out_words = out_words;
+        a.out = d_out;
+        a.ctrl = static_cast<uint32_t *>(d_workspace);
+        e = wah::launch_decode_segments(a, s);
+    }
+    if (e != hipSuccess) {
+        set_err("segment decode launch", e);
+        return WAH_ERR_HIP;
+    }
+    return WAH_OK;
+}
+
 // ---------------------------------------------------------------------------
 // host-pointer entry points (the reference's API)
 // ---------------------------------------------------------------------------

@@ -86,6 +86,18 @@ struct ExpandArgs {
     uint32_t parts; // workgroups that share one tile's output segments (set by the launcher)
 };
 
+// wah_decompress_segments_device: decode a range of segments through the index of wah_compress_device_indexed
+struct SegmentsArgs {
+    const uint32_t *comp;
+    uint64_t c_words;
+    const uint64_t *seg_offsets; // first compressed word of every segment of the bitmap, then C
+    uint64_t first_segment, n_segments;
+    uint64_t groups;    // G of the whole bitmap
+    uint64_t out_words; // ceil(31 G / 32): where the bitmap's last segment is cut
+    uint32_t *out;      // receives segment first_segment at word 0
+    uint32_t *ctrl;
+};
+
 // wah_bitop_device: what the operands' decodes left behind, checked on the device before the combining pass
 struct PairCheck {
     const uint64_t *info_a, *info_b; // [decoded words, groups] of the two operands
@@ -103,6 +115,7 @@ hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s);
 int decode_sums_grid(uint32_t *d_ctrl, hipStream_t s);
 hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t n_tiles, hipStream_t s);
 hipError_t launch_clear(void *p, size_t bytes, hipStream_t s);
+hipError_t launch_decode_segments(const SegmentsArgs &a, hipStream_t s);
 
 // wah_merge_fills_device (after the sums pass): kept-word counts per tile, their scan, scatter, count fix-up
 struct MergeArgs {

@@ -118,6 +118,20 @@ int wah_compress_status(void *d_workspace, void *stream);
 int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                           uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Decoding through the segment index of wah_compress_device_indexed(): segments [first_segment, first_segment +
+ * n_segments) of the bitmap (992 words each, the bitmap's last one shorter) are written to d_out[0 ..).  A stream of
+ * compress() never lets a fill cross a segment (compress.cu:129-146: one block per 992 words, fills merged inside
+ * it), so with the index every segment is an independent job: no scan of the stream (the getCounts + scan half of
+ * decompress.cu:56-83 is what the index already holds), one pass, any sub-range.  n_words: length of the ORIGINAL
+ * bitmap; the whole bitmap decodes to wah_decoded_words(wah_max_compressed_words(n_words)) words like
+ * wah_decompress_device.  Only for streams of this library's (= the reference's) compress(): a range whose words do
+ * not make up exactly its segment, or an empty fill word, is reported as WAH_ERR_STREAM by wah_decompress_status().
+ * Workspace: wah_decompress_segments_workspace_bytes(), 256-byte aligned. */
+size_t wah_decompress_segments_workspace_bytes(void);
+int wah_decompress_segments_device(const uint32_t *d_comp, uint64_t c_words, const uint64_t *d_segment_offsets, uint64_t n_words,
+                                   uint64_t first_segment, uint64_t n_segments, uint32_t *d_out, uint64_t out_capacity_words,
+                                   void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* First half of the above only (getCounts + scan): fills d_out_info so a
  * caller that does not know the decoded size can allocate, then call
  * wah_decompress_device (which repeats the scan) or _expand_device. */

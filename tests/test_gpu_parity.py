@@ -585,6 +585,87 @@ def test_column_matrix_one_launch(wah, oracle):
         wah.columns.compress_column_matrix(comp, matrix[:, :991].contiguous())
 
 
+def _indexed_stream(wah, d_in):
+    comp = wah.DeviceCompressor(d_in.numel(), indexed=True)
+    comp.run(d_in)
+    return comp.result().clone(), comp.seg_offsets.clone()
+
+
+@pytest.mark.parametrize("n", [1, 31, 991, 992, 993, 992 * 3 + 17, 992 * 64, 262144 + 5])
+def test_decode_segments_through_the_index(wah, oracle, n):
+    """wah_decompress_segments_device: with the segment index of the indexed compressor every 992-word segment decodes
+    on its own.  Whole bitmap == the oracle's decode of the stream; any sub-range == that slice."""
+    rng = np.random.default_rng(n)
+    for kind in ("sparse", "dense", "runs"):
+        if kind == "sparse":
+            a = oracle.gen_uniform(n, 3 + n, 0.01)
+        elif kind == "dense":
+            a = oracle.gen_uniform(n, 4 + n, 0.5)
+        else:
+            a = oracle.gen_clustered(n, 5 + n, 300)
+        stream, offs = _indexed_stream(wah, _dev(a))
+        want = oracle.decompress(_host(stream))
+        full = _host(wah.decompress_segments_device(stream, offs, n))
+        assert np.array_equal(full, want), kind
+        assert np.array_equal(full[:n], a), kind
+        segs = (wah.max_compressed_words(n) + 1023) // 1024
+        for _ in range(4):
+            first = int(rng.integers(0, segs))
+            count = int(rng.integers(0, segs - first + 1))
+            part = _host(wah.decompress_segments_device(stream, offs, n, first, count))
+            assert np.array_equal(part, want[first * 992: (first + count) * 992]), (kind, first, count)
+
+
+def test_decode_segments_rejects_what_is_not_a_segmented_stream(wah, oracle):
+    import torch
+
+    n = 992 * 40
+    a = oracle.gen_clustered(n, 77, 500)
+    stream, offs = _indexed_stream(wah, _dev(a))
+    with pytest.raises(wah.WahError):      # capacity
+        wah.decompress_segments_device(stream, offs, n, out=torch.empty(n - 1, dtype=torch.int32, device="cuda:0"))
+    with pytest.raises(wah.WahError):      # range outside the bitmap
+        wah.decompress_segments_device(stream, offs, n, 30, 20)
+    bad = offs.clone()
+    bad[7] += 1                            # segment 6 gets a word too many, segment 7 one too few
+    with pytest.raises(wah.WahError):
+        wah.decompress_segments_device(stream, bad, n)
+    bad = offs.clone()
+    bad[5], bad[6] = offs[6].item(), offs[5].item()   # not monotonic
+    with pytest.raises(wah.WahError):
+        wah.decompress_segments_device(stream, bad, n)
+    bad = offs.clone()
+    bad[-1] = stream.numel() + 5           # past the stream
+    with pytest.raises(wah.WahError):
+        wah.decompress_segments_device(stream, bad, n)
+    words = _host(stream).copy()
+    fills = np.flatnonzero(words & 0x80000000)
+    assert fills.size
+    words[fills[0]] += 3                   # a fill that is three groups too long
+    with pytest.raises(wah.WahError):
+        wah.decompress_segments_device(_dev(words), offs, n)
+    words = _host(stream).copy()
+    words[fills[0]] &= 0xC0000000          # an empty fill
+    with pytest.raises(wah.WahError):
+        wah.decompress_segments_device(_dev(words), offs, n)
+    # the untouched stream still decodes after all that
+    assert np.array_equal(_host(wah.decompress_segments_device(stream, offs, n))[:n], a)
+
+
+def test_decode_segments_full_size(wah):
+    """BASELINE size (1 GiB bitmap): index decode == the bitmap, for the three bench distributions."""
+    import torch
+
+    n = 992 * 1024 * 264
+    for c in range(3):
+        spec = wah.columns.column_spec(c, n, seed=9)
+        col = wah.columns.make_column(wah, spec, "cuda:0")
+        stream, offs = _indexed_stream(wah, col)
+        back = wah.decompress_segments_device(stream, offs, n)
+        assert bool(torch.equal(back[:n], col)), spec.kind
+        del stream, offs, back, col
+
+
 # ---------------------------------------------------------------- the reference's own test code
 def test_reference_tests_cpp_against_hip_library(wah):
     """oracle/_ref/ref_tests_hip = /root/reference/tests.cpp compiled in the authoring container and linked
