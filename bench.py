@@ -248,6 +248,24 @@ def main():
     copy_gbps = 5 * 8.0 * n / (ce[0].elapsed_time(ce[1]) * 1e-3) / 1e9
     del scratch
 
+    # side measurement, not part of `value`: the same bitmap decoded through the compressor's segment index
+    # (wah_decompress_segments_device: one pass, no sums kernel) -- what an engine that keeps the index gets
+    icomp = wah.DeviceCompressor(n, device=dev, indexed=True)
+    icomp.run(d_in)
+    istream = icomp.result()
+    seg_ws = torch.empty(int(wah.lib().wah_decompress_segments_workspace_bytes()), dtype=torch.uint8, device=dev)
+    for _ in range(2):
+        back = wah.decompress_segments_device(istream, icomp.seg_offsets, n, out=dec.out, workspace=seg_ws, check=False)
+    ie = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ie[0].record()
+    for _ in range(5):
+        wah.decompress_segments_device(istream, icomp.seg_offsets, n, out=dec.out, workspace=seg_ws, check=False)
+    ie[1].record()
+    torch.cuda.synchronize()
+    idx_ms = ie[0].elapsed_time(ie[1]) / 5
+    assert torch.equal(back[:n], d_in), "index decode mismatch"
+    del icomp, istream, back
+
     if rank == 0:
         in_bytes = 4.0 * n
         groups = (32 * n + 30) // 31
@@ -280,6 +298,12 @@ def main():
                                     "frac": round(achieved_d / HBM_PEAK_GBPS, 4),
                                     "traffic": tr.get("decompress_bytes_per_launch"),
                                     "algorithmic_bytes_per_launch": algo_d, "launch_ms": round(dec_avg, 4)},
+            "roofline_decompress_indexed": {"kernel": "decode_segments_kernel", "bound": "hbm",
+                                            "achieved": round(algo_d / (idx_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                                            "unit": "GB/s", "frac": round(algo_d / (idx_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                            "traffic": None, "algorithmic_bytes_per_launch": algo_d,
+                                            "launch_ms": round(idx_ms, 4),
+                                            "note": "side measurement with the segment index kept by the compressor; not part of value"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, param, args.cpu_sample_mib, args.seed)

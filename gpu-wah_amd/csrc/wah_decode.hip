@@ -599,28 +599,46 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
 // One wavefront per segment: all loads of its words (at most 1024, 4 KiB) are issued before the first one is used,
 // the words are parked in LDS, and the expansion gathers from there.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kSegDecodeWaves = 4;
+#ifndef WAH_SEG_WAVES
+#define WAH_SEG_WAVES 4
+#endif
+constexpr int kSegDecodeWaves = WAH_SEG_WAVES;
 
-// segment first_segment + k of the bitmap -> a.out + 992 k
-__device__ __forceinline__ void decode_one_segment(const SegmentsArgs &a, u64 k, unsigned char *flag, u32 *words, u32 lane) {
-    const u64 seg = a.first_segment + k;
-    const u64 w0 = uniform64(a.seg_offsets[seg]), w1 = uniform64(a.seg_offsets[seg + 1]);
+constexpr int kSegBatches = kSegGroups / 128;
+
+// where segment `seg` of the bitmap lies in the stream
+struct SegRange {
+    u64 w0;
+    u32 cnt, nvalid;
+    bool bad;
+};
+__device__ __forceinline__ SegRange seg_range(const SegmentsArgs &a, u64 seg, u64 w0, u64 w1) {
+    SegRange r;
     const u64 g0 = seg * kSegGroups;
-    const u32 nvalid = a.groups - g0 < kSegGroups ? (u32)(a.groups - g0) : kSegGroups;
+    r.nvalid = a.groups - g0 < kSegGroups ? (u32)(a.groups - g0) : kSegGroups;
     // every word of a compress() stream covers at least one group
-    bool bad = w1 < w0 || w1 > a.c_words || w1 - w0 > nvalid;
-    const u32 cnt = bad ? 0u : (u32)(w1 - w0);
-    const u32 *src = a.comp + w0;
-
-    // ---- the segment's words: 128 per batch, two per lane (reads past the range return 0) ---------------------------
-    constexpr int kBatches = kSegGroups / 128;
-    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(src, cnt * 4u);
-    u32 x0[kBatches], x1[kBatches];
+    r.bad = w1 < w0 || w1 > a.c_words || w1 - w0 > r.nvalid;
+    r.cnt = r.bad ? 0u : (u32)(w1 - w0);
+    r.w0 = w0;
+    return r;
+}
+// the segment's words: 128 per batch, two per lane (reads past the range return 0)
+__device__ __forceinline__ void seg_load_words(const SegmentsArgs &a, const SegRange &r, u32 (&x0)[kSegBatches], u32 (&x1)[kSegBatches], u32 lane) {
+    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(a.comp + r.w0, r.cnt * 4u);
 #pragma unroll
-    for (int b = 0; b < kBatches; ++b) {
+    for (int b = 0; b < kSegBatches; ++b) {
         x0[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u, 0, 0);
         x1[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u + 4u, 0, 0);
     }
+}
+
+// segment first_segment + k of the bitmap, its words in x0/x1 -> a.out + 992 k
+__device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const SegRange &rg, const u32 (&x0)[kSegBatches],
+                                           const u32 (&x1)[kSegBatches], unsigned char *flag, u32 *words, u32 lane) {
+    constexpr int kBatches = kSegBatches;
+    const u64 seg = a.first_segment + k;
+    const u32 cnt = rg.cnt, nvalid = rg.nvalid;
+    bool bad = rg.bad;
     reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
@@ -683,15 +701,22 @@ __device__ __forceinline__ void decode_one_segment(const SegmentsArgs &a, u64 k,
     }
 }
 
-// One segment per wavefront and no loop: looping over several segments per wavefront (2, 4, 8) was measured 20-30 %
-// slower -- the compiler hoists the lane constants out of the loop (100 registers; 71 when capped), and short-lived
-// wavefronts that start with their loads overlap better than long-lived ones.
+// One segment per wavefront and no loop.  Measured alternatives, both slower (1 GiB, sparse / clustered / dense:
+// 0.29 / 0.29 / 0.36 ms as it is): several segments per wavefront (2, 4, 8: 0.36-0.40 / 0.34-0.36 / 0.38-0.42 ms; the
+// compiler hoists the lane constants out of the loop, 100 registers, 71 when capped), and persistent wavefronts with
+// the next segment's words and the following offsets in flight during the expansion (0.47 / 0.42 / 0.51 ms,
+// tools/experiments/segments_stream.diff).  Short-lived wavefronts that begin with their loads overlap best.
 __global__ __launch_bounds__(kSegDecodeWaves * 64) void decode_segments_kernel(const SegmentsArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char s_flag[kSegDecodeWaves][kFlagBytes]; // 1: a word starts at this group
     __shared__ __attribute__((aligned(16))) u32 s_seg[kSegDecodeWaves][kSegGroups];           // the segment's words
-    const u32 wave = wave_id();
+    const u32 wave = wave_id(), lane = lane_id();
     const u64 k = (u64)blockIdx.x * kSegDecodeWaves + wave;
-    if (k < a.n_segments) decode_one_segment(a, k, s_flag[wave], s_seg[wave], lane_id());
+    if (k >= a.n_segments) return;
+    const u64 seg = a.first_segment + k;
+    const SegRange rg = seg_range(a, seg, uniform64(a.seg_offsets[seg]), uniform64(a.seg_offsets[seg + 1]));
+    u32 x0[kSegBatches], x1[kSegBatches];
+    seg_load_words(a, rg, x0, x1, lane);
+    seg_expand(a, k, rg, x0, x1, s_flag[wave], s_seg[wave], lane);
 }
 
 } // namespace
