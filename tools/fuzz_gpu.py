@@ -55,6 +55,17 @@ for seed in range(nc):
     if not np.array_equal(back[:n], data):
         bad += 1
         print("ROUND TRIP MISMATCH seed", seed, "n", n, "mode", mode)
+    # index decode: whole bitmap and a random range through the compressor's segment index
+    stream, offs = T._indexed_stream(wah, T._dev(data))
+    full = oracle.decompress(want)
+    segs = (wah.max_compressed_words(n) + 1023) // 1024
+    first = int(rng.integers(0, segs))
+    count = int(rng.integers(0, segs - first + 1))
+    if not np.array_equal(T._host(stream), want) or \
+            not np.array_equal(T._host(wah.decompress_segments_device(stream, offs, n)), full) or \
+            not np.array_equal(T._host(wah.decompress_segments_device(stream, offs, n, first, count)), full[first * 992: (first + count) * 992]):
+        bad += 1
+        print("INDEX DECODE MISMATCH seed", seed, "n", n, "mode", mode, first, count)
     if n >= 992 and seed % 3 == 0:  # bitwise operations against numpy on the decoded bitmaps
         other = oracle.gen_clustered(n, seed + 7, 900)
         for name, fn in (("and", np.bitwise_and), ("or", np.bitwise_or), ("xor", np.bitwise_xor), ("andnot", lambda x, y: x & ~y)):
