@@ -301,7 +301,8 @@ def main():
             "roofline_decompress_indexed": {"kernel": "decode_segments_kernel", "bound": "hbm",
                                             "achieved": round(algo_d / (idx_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                                             "unit": "GB/s", "frac": round(algo_d / (idx_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                                            "traffic": None, "algorithmic_bytes_per_launch": algo_d,
+                                            "traffic": tr.get("decompress_indexed_bytes_per_launch"),
+                                            "algorithmic_bytes_per_launch": algo_d,
                                             "launch_ms": round(idx_ms, 4),
                                             "note": "side measurement with the segment index kept by the compressor; not part of value"},
         }

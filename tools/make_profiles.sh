@@ -56,6 +56,7 @@ for wl in ("sparse", "clustered", "dense"):
     summary[wl] = {
         "compress_bytes_per_launch": hbm("compress_kernel"),
         "decompress_bytes_per_launch": hbm("decode_sums_kernel") + hbm("decode_expand_kernel"),
+        "decompress_indexed_bytes_per_launch": hbm("decode_segments_kernel"),
         "source": f"profiles/{os.path.basename(out).replace('profiles_', '')}_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md",
         "raw_KiB": tr,
     }
