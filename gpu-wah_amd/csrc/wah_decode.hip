@@ -644,13 +644,16 @@ __device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const S
 
     // ---- mark the group at which every word starts (as mark_pairs) ---------------------------------------------------
     const u32 fbase = (u32)(uintptr_t)(lds_u8_ptr)flag;
-    const u32 dump = fbase + kSegGroups + lane;
+    const u32 wbase = (u32)(uintptr_t)(lds_u8_ptr)reinterpret_cast<unsigned char *>(words);
     u32 pos = 0; // groups covered by the batches so far
     bool empty_word = false;
 #pragma unroll
     for (int b = 0; b < kBatches; ++b) {
         const u32 wi = 128u * b;
         if (wi < cnt) { // wave-uniform
+            // a lane without a word stores its flag byte into its own word slot instead, which is past the segment's
+            // words and never read (no dump area: 20 KiB of LDS per workgroup, eight workgroups per CU)
+            const u32 dump = wbase + (wi + 2u * lane) * 4u;
             const u32 i0 = wi + 2u * lane;
             const bool in0 = i0 < cnt, in1 = i0 + 1u < cnt;
             reinterpret_cast<uint2 *>(words)[64 * b + (int)lane] = make_uint2(x0[b], x1[b]);
@@ -664,7 +667,7 @@ __device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const S
             const u32 a0 = (u32)__mul24((int)(lo0 >> 6), -1023) + ((lo0 << 4) + fbase); // flag_slot(lo0), three instructions
             const u32 a1 = (u32)__mul24((int)(lo1 >> 6), -1023) + ((lo1 << 4) + fbase);
             *(lds_u8_ptr)(uintptr_t)(c0 ? a0 : dump) = 1;
-            *(lds_u8_ptr)(uintptr_t)(c1 ? a1 : dump) = 1;
+            *(lds_u8_ptr)(uintptr_t)(c1 ? a1 : dump + 4u) = 1;
             pos += (u32)__builtin_amdgcn_readlane((int)incl, 63);
         }
     }
@@ -707,7 +710,7 @@ __device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const S
 // the next segment's words and the following offsets in flight during the expansion (0.47 / 0.42 / 0.51 ms,
 // tools/experiments/segments_stream.diff).  Short-lived wavefronts that begin with their loads overlap best.
 __global__ __launch_bounds__(kSegDecodeWaves * 64) void decode_segments_kernel(const SegmentsArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kSegDecodeWaves][kFlagBytes]; // 1: a word starts at this group
+    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kSegDecodeWaves][kSegGroups]; // 1: a word starts at this group
     __shared__ __attribute__((aligned(16))) u32 s_seg[kSegDecodeWaves][kSegGroups];           // the segment's words
     const u32 wave = wave_id(), lane = lane_id();
     const u64 k = (u64)blockIdx.x * kSegDecodeWaves + wave;
