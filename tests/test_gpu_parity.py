@@ -583,6 +583,15 @@ def test_column_matrix_one_launch(wah, oracle):
     assert bool(torch.equal(back[: matrix.numel()].view(matrix.shape), matrix))
     with pytest.raises(ValueError):
         wah.columns.compress_column_matrix(comp, matrix[:, :991].contiguous())
+    # one column out of the batch, through the segment index: nothing else of the stream is read
+    segs = n // 992
+    for c in (0, 3, 6):
+        col = wah.decompress_segments_device(stream, comp.seg_offsets, matrix.numel(), c * segs, segs)
+        assert bool(torch.equal(col, matrix[c])), c
+    # ... and a stream that does not start at the allocation (4-byte aligned only)
+    shifted = torch.empty(stream.numel() + 3, dtype=torch.int32, device="cuda:0")[3:]
+    shifted.copy_(stream)
+    assert bool(torch.equal(wah.decompress_segments_device(shifted, comp.seg_offsets, matrix.numel(), 2 * segs, segs), matrix[2]))
 
 
 def _indexed_stream(wah, d_in):
