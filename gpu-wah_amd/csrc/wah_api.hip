@@ -111,6 +111,7 @@ struct HostCache {
     std::mutex m;
     void *buf[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[kSlots] = {0, 0, 0, 0, 0, 0};
+    int device = -1; // the device the kept buffers live on
     void release_locked() {
         for (int i = 0; i < kSlots; ++i) {
             if (buf[i]) (void)hipFree(buf[i]);
@@ -167,6 +168,12 @@ struct HostCall {
         return true;
     }
     bool init() {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (dev != cache.device) { // the caller moved to another GPU: buffers of the old one are of no use here
+            cache.release_locked();
+            cache.device = dev;
+        }
         return hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
     }
     void start() { (void)hipEventRecord(ev[0], nullptr); }
