@@ -37,6 +37,7 @@ from .api import (  # noqa: F401
     DeviceDecompressor,
     validate_device,
     bitop_device,
+    bitop_indexed_device,
     merge_fills_device,
     StreamReport,
     gen_uniform_device,

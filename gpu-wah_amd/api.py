@@ -51,6 +51,9 @@ ABI_SYMBOLS = {
     "wah_bitop_scratch_bytes": (_sz, [_u64, _u64, _u64]),
     "wah_bitop_device": (_int, [_int, _u64, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_bitop_status": (_int, [_vp, _u64, _u64, _u64, _vp]),
+    "wah_bitop_indexed_scratch_bytes": (_sz, [_u64]),
+    "wah_bitop_indexed_device": (_int, [_int, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _sz, _vp]),
+    "wah_bitop_indexed_status": (_int, [_vp, _u64, _vp]),
     "wah_gen_uniform_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_gen_clustered_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_copy_device": (_int, [_vp, _vp, _u64, _vp]),
@@ -343,6 +346,35 @@ def bitop_device(op, d_a, d_b, n_words):
                                   scratch.data_ptr(), sc_bytes, sp), "wah_bitop_device")
     _check(lib().wah_bitop_status(scratch.data_ptr(), n, ca, cb, sp), "bitop")
     return out[: int(count.item())].clone()
+
+
+def bitop_indexed_device(op, d_a, a_offsets, d_b, b_offsets, n_words, scratch=None, out=None, out_offsets=None, check=True):
+    """compress(A op B) from two compressed bitmaps that come with their segment indexes (wah_bitop_indexed_device).
+    Returns (stream, seg_offsets) of the result; scratch / out / out_offsets: reuse these tensors; check=False: only
+    enqueue and return (out, count tensor, out_offsets)."""
+    torch = _torch()
+    _as_words(torch, d_a)
+    _as_words(torch, d_b)
+    n = int(n_words)
+    cap = max_compressed_words(n)
+    n_seg = (cap + 1023) // 1024
+    sc_bytes = int(lib().wah_bitop_indexed_scratch_bytes(n))
+    if scratch is None:
+        scratch = torch.empty(sc_bytes, dtype=torch.uint8, device=d_a.device)
+    if out is None:
+        out = torch.empty(max(cap, 1), dtype=torch.int32, device=d_a.device)
+    if out_offsets is None:
+        out_offsets = torch.zeros(n_seg + 1, dtype=torch.int64, device=d_a.device)
+    count = torch.zeros(1, dtype=torch.int64, device=d_a.device)
+    sp = _stream_ptr(torch)
+    _check(lib().wah_bitop_indexed_device(OPS[op], n, d_a.data_ptr(), d_a.numel(), a_offsets.data_ptr(), d_b.data_ptr(),
+                                          d_b.numel(), b_offsets.data_ptr(), out.data_ptr(), out.numel(), count.data_ptr(),
+                                          out_offsets.data_ptr(), scratch.data_ptr(), scratch.numel(), sp),
+           "wah_bitop_indexed_device")
+    if not check:
+        return out, count, out_offsets
+    _check(lib().wah_bitop_indexed_status(scratch.data_ptr(), n, sp), "bitop_indexed")
+    return out[: int(count.item())], out_offsets
 
 
 StreamReport = collections.namedtuple(

@@ -713,6 +713,82 @@ int wah_decompress_segments_device(const uint32_t *d_comp, uint64_t c_words, con
     return WAH_OK;
 }
 
+namespace {
+// scratch of wah_bitop_indexed_device: [control block of the combining pass][combined decoded bitmap][compress workspace]
+struct BitopIndexedLayout {
+    size_t bitmap, ws_c, total;
+    size_t ws_c_bytes;
+    uint64_t decoded_capacity;
+};
+BitopIndexedLayout bitop_indexed_layout(uint64_t n_words) {
+    BitopIndexedLayout l;
+    l.decoded_capacity = n_words + 1; // ceil(31 G / 32) is n_words or n_words + 1
+    l.ws_c_bytes = wah_compress_workspace_bytes(n_words);
+    l.bitmap = round256(wah::kCtlWords * sizeof(uint32_t));
+    l.ws_c = l.bitmap + round256(l.decoded_capacity * sizeof(uint32_t));
+    l.total = l.ws_c + round256(l.ws_c_bytes);
+    return l;
+}
+} // namespace
+
+size_t wah_bitop_indexed_scratch_bytes(uint64_t n_words) { return bitop_indexed_layout(n_words).total; }
+
+int wah_bitop_indexed_device(int op, uint64_t n_words, const uint32_t *d_a, uint64_t a_words, const uint64_t *d_a_offsets,
+                             const uint32_t *d_b, uint64_t b_words, const uint64_t *d_b_offsets, uint32_t *d_out,
+                             uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_out_offsets, void *d_scratch,
+                             size_t scratch_bytes, void *stream) {
+    g_err[0] = 0;
+    if (op < WAH_OP_AND || op > WAH_OP_ANDNOT || !d_scratch || (reinterpret_cast<uintptr_t>(d_scratch) & 255u)) {
+        set_err("bad operation or scratch pointer");
+        return WAH_ERR_ARG;
+    }
+    if (!d_a_offsets || !d_b_offsets || (a_words && !d_a) || (b_words && !d_b) || n_words >= (1ull << 40) ||
+        a_words >= (1ull << 40) || b_words >= (1ull << 40) || (reinterpret_cast<uintptr_t>(d_a) & 3u) ||
+        (reinterpret_cast<uintptr_t>(d_b) & 3u)) {
+        set_err("null or misaligned operand");
+        return WAH_ERR_ARG;
+    }
+    const BitopIndexedLayout l = bitop_indexed_layout(n_words);
+    if (scratch_bytes < l.total) {
+        set_err("scratch too small");
+        return WAH_ERR_WORKSPACE;
+    }
+    char *sc = static_cast<char *>(d_scratch);
+    uint32_t *combined = reinterpret_cast<uint32_t *>(sc + l.bitmap);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t groups = wah_max_compressed_words(n_words);
+    hipError_t e = wah::launch_clear(sc, wah::kCtlWords * sizeof(uint32_t), s);
+    if (e == hipSuccess) {
+        wah::BitopSegArgs a = {};
+        a.a.comp = d_a;
+        a.a.c_words = a_words;
+        a.a.seg_offsets = d_a_offsets;
+        a.a.first_segment = 0;
+        a.a.n_segments = (groups + wah::kSegGroups - 1) / wah::kSegGroups;
+        a.a.groups = groups;
+        a.a.out_words = wah_decoded_words(groups);
+        a.a.out = combined;
+        a.a.ctrl = reinterpret_cast<uint32_t *>(sc);
+        a.comp_b = d_b;
+        a.c_words_b = b_words;
+        a.seg_offsets_b = d_b_offsets;
+        a.op = op;
+        e = wah::launch_bitop_segments(a, s);
+    }
+    if (e != hipSuccess) {
+        set_err("combining pass launch", e);
+        return WAH_ERR_HIP;
+    }
+    return compress_device_impl(combined, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, d_out_offsets,
+                                sc + l.ws_c, l.ws_c_bytes, stream);
+}
+
+int wah_bitop_indexed_status(void *d_scratch, uint64_t n_words, void *stream) {
+    if (!d_scratch) return WAH_ERR_ARG;
+    const int rc = read_status(d_scratch, stream); // the combining pass: operands that are not segmented streams of n_words
+    return rc != WAH_OK ? rc : read_status(static_cast<char *>(d_scratch) + bitop_indexed_layout(n_words).ws_c, stream);
+}
+
 // ---------------------------------------------------------------------------
 // host-pointer entry points (the reference's API)
 // ---------------------------------------------------------------------------

@@ -632,23 +632,20 @@ __device__ __forceinline__ void seg_load_words(const SegmentsArgs &a, const SegR
     }
 }
 
-// segment first_segment + k of the bitmap, its words in x0/x1 -> a.out + 992 k
-__device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const SegRange &rg, const u32 (&x0)[kSegBatches],
-                                           const u32 (&x1)[kSegBatches], unsigned char *flag, u32 *words, u32 lane) {
-    constexpr int kBatches = kSegBatches;
-    const u64 seg = a.first_segment + k;
+// Mark phase of one segment: parks its words (x0/x1, two per lane and batch) in `words` and flags the group at which
+// every word starts (as mark_pairs).  Returns false when the range is not exactly this segment: the words must add up
+// to nvalid groups, none of them empty -- then the r-th flag is the r-th word.
+__device__ __forceinline__ bool seg_mark(const SegRange &rg, const u32 (&x0)[kSegBatches], const u32 (&x1)[kSegBatches],
+                                         unsigned char *flag, u32 *words, u32 lane) {
     const u32 cnt = rg.cnt, nvalid = rg.nvalid;
-    bool bad = rg.bad;
     reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-    // ---- mark the group at which every word starts (as mark_pairs) ---------------------------------------------------
     const u32 fbase = (u32)(uintptr_t)(lds_u8_ptr)flag;
     const u32 wbase = (u32)(uintptr_t)(lds_u8_ptr)reinterpret_cast<unsigned char *>(words);
     u32 pos = 0; // groups covered by the batches so far
     bool empty_word = false;
 #pragma unroll
-    for (int b = 0; b < kBatches; ++b) {
+    for (int b = 0; b < kSegBatches; ++b) {
         const u32 wi = 128u * b;
         if (wi < cnt) { // wave-uniform
             // a lane without a word stores its flag byte into its own word slot instead, which is past the segment's
@@ -672,36 +669,56 @@ __device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const S
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // the words of the range must make up exactly this segment, none of them empty: then the r-th flag is the r-th word
-    bad = bad || pos != nvalid || __ballot(empty_word) != 0;
-    if (bad) {
+    return !(rg.bad || pos != nvalid || __ballot(empty_word) != 0);
+}
+
+// Step s of the expansion (expand_steps()): the 31-bit group 64 s + lane of a marked segment.  f: the lane's 16 flag
+// bytes; before: flags in earlier steps - 1 (carried from step to step).
+__device__ __forceinline__ u32 seg_group(int s, const u32 (&f)[4], u32 &before, const u32 *words, u32 cnt, u32 nvalid, u32 lane) {
+    const u32 fb = (f[s >> 2] >> (8 * (s & 3))) & 0xFFu;
+    const u64 m = __ballot(fb != 0u);
+    const u32 r = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, fb)) + before;
+    before = (u32)__builtin_amdgcn_readlane((int)r, 63);
+    const u32 src_word = words[min(r, cnt - 1u)];
+    const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
+    u32 grp = (int)src_word < 0 ? fill_val : src_word;
+    if ((u32)(64 * s) + lane >= nvalid) grp = 0u;
+    return grp;
+}
+
+// where the 992 words of segment first_segment + k go, and the lane constants of the 31 -> 32 repack
+struct SegStore {
+    __amdgpu_buffer_rsrc_t rsrc;
+    u32 o, up, soff;
+};
+__device__ __forceinline__ SegStore seg_store_setup(u32 *out, u64 out_words, u64 seg, u64 k, u32 lane) {
+    SegStore st;
+    const u64 seg_w0 = seg * kSegWords;
+    const u32 seg_words = out_words > seg_w0 ? (u32)(out_words - seg_w0 < kSegWords ? out_words - seg_w0 : kSegWords) : 0u;
+    st.rsrc = make_rsrc(out + k * kSegWords, seg_words * 4u); // stores past the end are dropped
+    st.o = lane & 31u;
+    st.up = 31u - ((lane - 1u) & 31u);
+    st.soff = st.o != 31u ? (lane - (lane >> 5)) * 4u : 0xFFFFF000u; // lanes 31, 63 only lend their group
+    return st;
+}
+__device__ __forceinline__ void seg_store(const SegStore &st, int s, u32 grp) {
+    const u32 hi_part = (u32)__builtin_amdgcn_mov_dpp((int)(grp << st.up), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    __builtin_amdgcn_raw_buffer_store_b32((grp >> st.o) | hi_part, st.rsrc, st.soff + 248u * s, 0, 0);
+}
+
+// segment first_segment + k of the bitmap, its words in x0/x1 -> a.out + 992 k
+__device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const SegRange &rg, const u32 (&x0)[kSegBatches],
+                                           const u32 (&x1)[kSegBatches], unsigned char *flag, u32 *words, u32 lane) {
+    if (!seg_mark(rg, x0, x1, flag, words, lane)) {
         if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
         return;
     }
-
-    // ---- expand: the 16 steps of expand_steps() -----------------------------------------------------------------------
-    const u64 seg_w0 = seg * kSegWords;
-    const u32 seg_words = a.out_words > seg_w0 ? (u32)(a.out_words - seg_w0 < kSegWords ? a.out_words - seg_w0 : kSegWords) : 0u;
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + k * kSegWords, seg_words * 4u); // stores past the end are dropped
-    const u32 o = lane & 31u;
-    const u32 up = 31u - ((lane - 1u) & 31u);
-    const u32 soff = o != 31u ? (lane - (lane >> 5)) * 4u : 0xFFFFF000u; // lanes 31, 63 only lend their group
+    const SegStore st = seg_store_setup(a.out, a.out_words, a.first_segment + k, k, lane);
     const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
     const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
-    u32 before = 0xFFFFFFFFu; // flags in earlier steps - 1
+    u32 before = 0xFFFFFFFFu;
 #pragma unroll
-    for (int s = 0; s < (int)kSteps; ++s) {
-        const u32 fb = (f[s >> 2] >> (8 * (s & 3))) & 0xFFu;
-        const u64 m = __ballot(fb != 0u);
-        const u32 r = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, fb)) + before;
-        before = (u32)__builtin_amdgcn_readlane((int)r, 63);
-        const u32 src_word = words[min(r, cnt - 1u)];
-        const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
-        u32 grp = (int)src_word < 0 ? fill_val : src_word;
-        if ((u32)(64 * s) + lane >= nvalid) grp = 0u;
-        const u32 hi_part = (u32)__builtin_amdgcn_mov_dpp((int)(grp << up), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-        __builtin_amdgcn_raw_buffer_store_b32((grp >> o) | hi_part, rsrc, soff + 248u * s, 0, 0);
-    }
+    for (int s = 0; s < (int)kSteps; ++s) seg_store(st, s, seg_group(s, f, before, words, rg.cnt, rg.nvalid, lane));
 }
 
 // One segment per wavefront and no loop.  Measured alternatives, both slower (1 GiB, sparse / clustered / dense:
@@ -720,6 +737,59 @@ __global__ __launch_bounds__(kSegDecodeWaves * 64) void decode_segments_kernel(c
     u32 x0[kSegBatches], x1[kSegBatches];
     seg_load_words(a, rg, x0, x1, lane);
     seg_expand(a, k, rg, x0, x1, s_flag[wave], s_seg[wave], lane);
+}
+
+// wah_bitop_indexed_device: the same segment of TWO indexed streams, combined group by group, written as decoded words.
+// Operand A is expanded into 16 registers, the LDS areas are then reused for operand B, whose groups are combined
+// with A's as they come out: still 20 KiB of LDS per workgroup, one pass over both streams, ONE decoded bitmap written
+// (the general route, wah_bitop_device, writes two and reads them back).
+__global__ __launch_bounds__(kSegDecodeWaves * 64) void bitop_segments_kernel(const BitopSegArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kSegDecodeWaves][kSegGroups];
+    __shared__ __attribute__((aligned(16))) u32 s_seg[kSegDecodeWaves][kSegGroups];
+    const u32 wave = wave_id(), lane = lane_id();
+    const u64 k = (u64)blockIdx.x * kSegDecodeWaves + wave;
+    if (k >= a.a.n_segments) return;
+    const u64 seg = a.a.first_segment + k;
+    SegmentsArgs sb = a.a; // operand B: same bitmap geometry, its own stream and index
+    sb.comp = a.comp_b;
+    sb.c_words = a.c_words_b;
+    const SegRange ra = seg_range(a.a, seg, uniform64(a.a.seg_offsets[seg]), uniform64(a.a.seg_offsets[seg + 1]));
+    const SegRange rb = seg_range(sb, seg, uniform64(a.seg_offsets_b[seg]), uniform64(a.seg_offsets_b[seg + 1]));
+    u32 x0[kSegBatches], x1[kSegBatches], y0[kSegBatches], y1[kSegBatches];
+    seg_load_words(a.a, ra, x0, x1, lane);
+    seg_load_words(sb, rb, y0, y1, lane);
+    unsigned char *flag = s_flag[wave];
+    u32 *words = s_seg[wave];
+
+    bool ok = seg_mark(ra, x0, x1, flag, words, lane);
+    u32 ga[kSteps];
+    {
+        const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
+        const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
+        u32 before = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = 0; s < (int)kSteps; ++s) ga[s] = seg_group(s, f, before, words, ok ? ra.cnt : 1u, ra.nvalid, lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // A's words and flags have been read: the areas go to B
+    ok = seg_mark(rb, y0, y1, flag, words, lane) && ok;
+    if (!ok) {
+        if (lane == 0) atomicOr(a.a.ctrl + kCtlError, kErrStream);
+        return;
+    }
+    // any of the four operations (include/wah.h: WAH_OP_AND 0, OR 1, XOR 2, ANDNOT 3) as a sum of minterms; the masks
+    // are wave-uniform
+    const u32 k_ab = a.op <= 1 ? ~0u : 0u;
+    const u32 k_a_nb = a.op == 0 ? 0u : ~0u;
+    const u32 k_na_b = a.op == 1 || a.op == 2 ? ~0u : 0u;
+    const SegStore st = seg_store_setup(a.a.out, a.a.out_words, seg, k, lane);
+    const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
+    const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
+    u32 before = 0xFFFFFFFFu;
+#pragma unroll
+    for (int s = 0; s < (int)kSteps; ++s) {
+        const u32 gb = seg_group(s, f, before, words, rb.cnt, rb.nvalid, lane);
+        seg_store(st, s, (ga[s] & gb & k_ab) | (ga[s] & ~gb & k_a_nb) | (~ga[s] & gb & k_na_b));
+    }
 }
 
 } // namespace
@@ -777,6 +847,13 @@ hipError_t launch_decode_segments(const SegmentsArgs &a, hipStream_t s) {
     if (a.n_segments == 0) return hipSuccess;
     const u64 grid = (a.n_segments + kSegDecodeWaves - 1) / kSegDecodeWaves;
     hipLaunchKernelGGL(decode_segments_kernel, dim3((unsigned)grid), dim3(kSegDecodeWaves * 64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_bitop_segments(const BitopSegArgs &a, hipStream_t s) {
+    if (a.a.n_segments == 0) return hipSuccess;
+    const u64 grid = (a.a.n_segments + kSegDecodeWaves - 1) / kSegDecodeWaves;
+    hipLaunchKernelGGL(bitop_segments_kernel, dim3((unsigned)grid), dim3(kSegDecodeWaves * 64), 0, s, a);
     return hipGetLastError();
 }
 

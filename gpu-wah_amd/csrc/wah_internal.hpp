@@ -98,6 +98,15 @@ struct SegmentsArgs {
     uint32_t *ctrl;
 };
 
+// wah_bitop_indexed_device: operand A as SegmentsArgs (its `out` receives the combined decoded words), operand B beside it
+struct BitopSegArgs {
+    SegmentsArgs a;
+    const uint32_t *comp_b;
+    uint64_t c_words_b;
+    const uint64_t *seg_offsets_b;
+    int op; // WAH_OP_*
+};
+
 // wah_bitop_device: what the operands' decodes left behind, checked on the device before the combining pass
 struct PairCheck {
     const uint64_t *info_a, *info_b; // [decoded words, groups] of the two operands
@@ -116,6 +125,7 @@ int decode_sums_grid(uint32_t *d_ctrl, hipStream_t s);
 hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t n_tiles, hipStream_t s);
 hipError_t launch_clear(void *p, size_t bytes, hipStream_t s);
 hipError_t launch_decode_segments(const SegmentsArgs &a, hipStream_t s);
+hipError_t launch_bitop_segments(const BitopSegArgs &a, hipStream_t s);
 
 // wah_merge_fills_device (after the sums pass): kept-word counts per tile, their scan, scatter, count fix-up
 struct MergeArgs {

@@ -194,6 +194,20 @@ int wah_bitop_device(int op, uint64_t n_words, const uint32_t *d_a, uint64_t a_w
                      void *d_scratch, size_t scratch_bytes, void *stream);
 int wah_bitop_status(void *d_scratch, uint64_t n_words, uint64_t a_words, uint64_t b_words, void *stream);
 
+/* The same for operands that come with their segment index (wah_compress_device_indexed): the two streams are walked
+ * segment by segment through their indexes, combined group by group in registers, and ONE decoded bitmap is written,
+ * which the compress kernel then reads -- no scan of the operands, no second read of them, half the intermediate
+ * traffic of wah_bitop_device.  d_out_offsets (may be NULL) receives the result's own segment index, so results can
+ * be combined further.  Operands must be streams of compress() for bitmaps of n_words words (anything else:
+ * WAH_ERR_STREAM from wah_bitop_indexed_status()).
+ *   d_scratch: wah_bitop_indexed_scratch_bytes(n_words) bytes, 256-byte aligned. */
+size_t wah_bitop_indexed_scratch_bytes(uint64_t n_words);
+int wah_bitop_indexed_device(int op, uint64_t n_words, const uint32_t *d_a, uint64_t a_words, const uint64_t *d_a_offsets,
+                             const uint32_t *d_b, uint64_t b_words, const uint64_t *d_b_offsets, uint32_t *d_out,
+                             uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_out_offsets, void *d_scratch,
+                             size_t scratch_bytes, void *stream);
+int wah_bitop_indexed_status(void *d_scratch, uint64_t n_words, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Benchmark support: synthetic bitmaps generated in HBM (include/wah_gen.h
  * states the bit-exact definition; replaces tests.cpp:42-64), and a plain

@@ -374,6 +374,45 @@ def test_bitops_on_compressed_bitmaps(wah, oracle):
         wah.bitop_device("and", _dev(oracle.compress(a)), _dev(oracle.compress(a[:992 * 9])), a.size)
 
 
+def test_bitops_through_the_segment_indexes(wah, oracle):
+    """wah_bitop_indexed_device(op, A + index, B + index) == compress(A op B), and the result's own index is right
+    (so results chain: (A and B) or C)."""
+    ops = {"and": np.bitwise_and, "or": np.bitwise_or, "xor": np.bitwise_xor, "andnot": lambda x, y: x & ~y}
+    for n in (992 * 64, 992 * 300 + 17, 5, 992):
+        a = oracle.gen_uniform(n, 21, 0.05)
+        b = oracle.gen_clustered(n, 22, 700)
+        c = oracle.gen_uniform(n, 23, 0.5)
+        (sa, oa), (sb, ob), (sc, oc) = (_indexed_stream(wah, _dev(x)) for x in (a, b, c))
+        for name, fn in ops.items():
+            want = oracle.compress(fn(a, b).astype(np.uint32))
+            got, offs = wah.bitop_indexed_device(name, sa, oa, sb, ob, n)
+            assert got.numel() == want.size and np.array_equal(_host(got), want), (n, name)
+            ref_stream, ref_offs = _indexed_stream(wah, _dev(fn(a, b).astype(np.uint32)))
+            assert np.array_equal(offs.cpu().numpy(), ref_offs.cpu().numpy()), (n, name)
+        ab, oab = wah.bitop_indexed_device("and", sa, oa, sb, ob, n)
+        abc, _ = wah.bitop_indexed_device("or", ab.clone(), oab.clone(), sc, oc, n)
+        assert np.array_equal(_host(abc), oracle.compress(((a & b) | c).astype(np.uint32))), n
+    # operands of another length, or an index that does not belong to the stream, are refused
+    a = oracle.gen_uniform(992 * 10, 1, 0.1)
+    sa, oa = _indexed_stream(wah, _dev(a))
+    sb, ob = _indexed_stream(wah, _dev(a[: 992 * 9]))
+    with pytest.raises(wah.WahError):
+        wah.bitop_indexed_device("and", sa, oa, sb, torch_pad(ob, oa.numel()), a.size)
+    bad = oa.clone()
+    bad[3] += 1
+    with pytest.raises(wah.WahError):
+        wah.bitop_indexed_device("xor", sa, bad, sa, oa, a.size)
+    with pytest.raises(wah.WahError):
+        wah.bitop_indexed_device("xor", sa, oa, sa, bad, a.size)
+
+
+def torch_pad(t, n):
+    """t extended to n entries by repeating its last one (an index that claims more segments than the stream has)."""
+    import torch
+
+    return torch.cat([t, t[-1:].expand(n - t.numel())]) if t.numel() < n else t
+
+
 # ---------------------------------------------------------------- API behaviour
 def test_reusable_workspace_and_indexed_output(wah, oracle):
     """Same DeviceCompressor run repeatedly (control block re-zeroed every launch) + the segment index."""

@@ -74,6 +74,11 @@ for seed in range(nc):
             if g.shape != w.shape or not np.array_equal(g, w):
                 bad += 1
                 print("BITOP MISMATCH seed", seed, name, "n", n)
+            so, oo = T._indexed_stream(wah, T._dev(other))
+            gi, _ = wah.bitop_indexed_device(name, stream, offs, so, oo, n)
+            if gi.numel() != w.size or not np.array_equal(T._host(gi), w):
+                bad += 1
+                print("INDEXED BITOP MISMATCH seed", seed, name, "n", n)
     if seed % 10 == 0:
         print("compress seed", seed, "bad =", bad, f"{time.time() - t0:.0f}s", flush=True)
 print("done, mismatches:", bad)
