@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 wah = importlib.import_module("gpu-wah_amd")
-probe = ctypes.CDLL(os.path.join(ROOT, "tools/scratch/libwah_probe.so"))
+probe = ctypes.CDLL(os.path.join(ROOT, "tools/scratch/libwah_probe0.so"))
 probe.wah_probe_compress_padded.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 n = 992 * 1024 * 264
 segs = n // 992
