@@ -5,8 +5,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 wah = importlib.import_module("gpu-wah_amd")
-l = ctypes.CDLL(os.path.join(ROOT, "tools/scratch/libwah_probe6.so"))
-l.wah_probe_compress_padded.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+libs = {}
+for v in (sys.argv[1:] or ["6"]):  # 6: {word, position} compaction + finalize; 7: final words in LDS, plain copy out
+    l = ctypes.CDLL(os.path.join(ROOT, f"tools/scratch/libwah_probe{v}.so"))
+    l.wah_probe_compress_padded.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    libs[v] = l
 n = 992 * 1024 * 264
 out = torch.zeros(wah.max_compressed_words(n) + 1024, dtype=torch.int32, device="cuda")
 for c in range(3):
@@ -18,8 +21,12 @@ for c in range(3):
     offs = comp.seg_offsets.clone()
     s = torch.cuda.current_stream().cuda_stream
     res = {}
-    for name, fn in (("compress_kernel", lambda: comp.run(col)),
-                     ("known offsets", lambda: l.wah_probe_compress_padded(col.data_ptr(), n, out.data_ptr(), offs.data_ptr(), s))):
+    cases = [("compress_kernel", lambda: comp.run(col))]
+    for v, l in libs.items():
+        cases.append((f"known offsets v{v}", (lambda l: lambda: l.wah_probe_compress_padded(col.data_ptr(), n, out.data_ptr(), offs.data_ptr(), s))(l)))
+    for name, fn in cases:
+        if name != "compress_kernel":
+            out.zero_()
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -30,6 +37,7 @@ for c in range(3):
         ev[1].record()
         torch.cuda.synchronize()
         res[name] = ev[0].elapsed_time(ev[1]) / 10
-    assert torch.equal(out[: stream.numel()], stream), "stream differs"
-    print(f"{spec.kind:9s}: compress_kernel {res['compress_kernel']:.4f} ms, known offsets {res['known offsets']:.4f} ms", flush=True)
+        if name != "compress_kernel":
+            assert torch.equal(out[: stream.numel()], stream), name + ": stream differs"
+    print(f"{spec.kind:9s}: " + ", ".join(f"{k} {v:.4f} ms" for k, v in res.items()), flush=True)
     del col, comp, stream, offs
