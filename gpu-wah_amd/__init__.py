@@ -33,6 +33,7 @@ from .api import (  # noqa: F401
     compress_device,
     decompress_device,
     decompress_segments_device,
+    build_index_device,
     DeviceCompressor,
     DeviceDecompressor,
     validate_device,

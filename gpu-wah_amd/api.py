@@ -42,6 +42,7 @@ ABI_SYMBOLS = {
     "wah_decompress_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_scan_device": (_int, [_vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_expand_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_build_index_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_segments_workspace_bytes": (_sz, []),
     "wah_decompress_segments_device": (ctypes.c_int, [_vp, _u64, _vp, _u64, _u64, _u64, _vp, _u64, _vp, _sz, _vp]),
     "wah_decompress_status": (_int, [_vp, _vp]),
@@ -282,6 +283,25 @@ def decompress_device(d_comp, out_capacity_words):
     d = DeviceDecompressor(d_comp.numel(), out_capacity_words, device=d_comp.device)
     d.run(d_comp)
     return d.result().clone()
+
+
+def build_index_device(d_comp):
+    """Segment index (int64 tensor, ceil(G / 1024) + 1 entries) of a stream of compress() that came without one, and its
+    group count G (wah_build_index_device).  Raises for streams that have no such index."""
+    torch = _torch()
+    _as_words(torch, d_comp)
+    c = int(d_comp.numel())
+    ws_bytes = int(lib().wah_decompress_workspace_bytes(c, 0))
+    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=d_comp.device)
+    info = torch.zeros(2, dtype=torch.int64, device=d_comp.device)
+    # a stream of c words has at most c segments (every segment holds at least one word)
+    offsets = torch.zeros(c + 1, dtype=torch.int64, device=d_comp.device)
+    sp = _stream_ptr(torch)
+    _check(lib().wah_build_index_device(d_comp.data_ptr(), c, offsets.data_ptr(), offsets.numel(), info.data_ptr(),
+                                        workspace.data_ptr(), ws_bytes, sp), "wah_build_index_device")
+    _check(lib().wah_decompress_status(workspace.data_ptr(), sp), "build_index")
+    groups = int(info[1].item())
+    return offsets[: (groups + 1023) // 1024 + 1].clone(), groups
 
 
 def decompress_segments_device(d_comp, seg_offsets, n_words, first_segment=0, n_segments=None, out=None, workspace=None,

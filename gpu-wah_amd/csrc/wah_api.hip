@@ -511,6 +511,37 @@ int wah_validate_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_re
     return WAH_OK;
 }
 
+int wah_build_index_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_segment_offsets, uint64_t offsets_capacity,
+                           uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (!d_segment_offsets || !d_out_info || offsets_capacity == 0) {
+        g_err[0] = 0;
+        set_err("null pointer or empty index");
+        return WAH_ERR_ARG;
+    }
+    // the sums pass: tile bases in the workspace, [decoded words, groups] in d_out_info
+    const int rc = decode_common(d_comp, c_words, nullptr, 0, d_out_info, d_workspace, workspace_bytes, stream, true, false);
+    if (rc != WAH_OK) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (c_words == 0) { // no groups, no segments: the index is the single entry 0
+        const hipError_t e = wah::launch_clear(d_segment_offsets, sizeof(uint64_t), s);
+        if (e != hipSuccess) {
+            set_err("clearing the index", e);
+            return WAH_ERR_HIP;
+        }
+        return WAH_OK;
+    }
+    const DecodeLayout l = decode_layout(c_words);
+    char *ws = static_cast<char *>(d_workspace);
+    const hipError_t e = wah::launch_build_index(d_comp, c_words, reinterpret_cast<const uint64_t *>(ws + l.base_off), d_out_info,
+                                                 d_segment_offsets, offsets_capacity, reinterpret_cast<uint32_t *>(ws + l.ctrl_off),
+                                                 l.n_tiles, s);
+    if (e != hipSuccess) {
+        set_err("index kernel launch", e);
+        return WAH_ERR_HIP;
+    }
+    return WAH_OK;
+}
+
 // ---- merged (unsegmented) form -------------------------------------------------------------------------------
 namespace {
 struct MergeLayout {

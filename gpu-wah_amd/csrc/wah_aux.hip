@@ -64,6 +64,51 @@ __global__ __launch_bounds__(kExpandThreads) void validate_kernel(const u32 *com
     }
 }
 
+// ===========================================================================
+// wah_build_index_device (include/wah.h): the segment index of a stream that came without one.  Same walk as the checker:
+// every word learns its group position; a word that starts on a multiple of 1024 groups is the first word of that
+// segment.  A fill across such a boundary, or an empty fill, means the stream has no segment index (kErrStream).
+// ===========================================================================
+__global__ __launch_bounds__(kExpandThreads) void index_kernel(const u32 *comp, u64 c_words, const u64 *tile_base, const u64 *info,
+                                                               u64 *offsets, u64 capacity, u32 *ctrl) {
+    __shared__ u64 s_wave_sum[kExpandWaves];
+    const u32 lane = lane_id();
+    const u32 wave = wave_id();
+    const u32 tile = blockIdx.x;
+    const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread; // my 16 consecutive words
+    u32 w[kExpandWordsPerThread];
+    u64 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        w[k] = w0 + k < c_words ? comp[w0 + k] : 0x80000000u; // past the end: nothing
+        mine += word_groups(w[k]);
+    }
+    const u64 incl = wave_scan_incl(mine, lane);
+    if (lane == 63) s_wave_sum[wave] = incl;
+    __syncthreads();
+    u64 p = tile_base[tile] + (incl - mine); // group position of my first word
+    for (u32 k = 0; k < wave; ++k) p += s_wave_sum[k];
+    const u64 n_seg = (info[1] + kSegGroups - 1) / kSegGroups;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < kExpandWordsPerThread; ++k) {
+        if (w0 + k < c_words) {
+            const u32 n = word_groups(w[k]);
+            const u32 in_seg = (u32)(p & (kSegGroups - 1u));
+            bad |= n == 0u || in_seg + n > kSegGroups;
+            if (in_seg == 0u && n != 0u && (p >> 10) < capacity) offsets[p >> 10] = w0 + k;
+            p += n;
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(ctrl + kCtlError, kErrStream);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n_seg < capacity)
+            offsets[n_seg] = c_words;
+        else
+            atomicOr(ctrl + kCtlError, kErrCapacity);
+    }
+}
+
 __global__ void validate_init_kernel(u64 *report) {
     if (threadIdx.x < 8) report[threadIdx.x] = threadIdx.x == 6 ? 1ull : 0ull;
 }
@@ -95,6 +140,12 @@ hipError_t launch_validate(const u32 *comp, u64 c_words, const u64 *tile_base, c
                            hipStream_t s) {
     hipLaunchKernelGGL(validate_init_kernel, dim3(1), dim3(64), 0, s, report);
     if (n_tiles) hipLaunchKernelGGL(validate_kernel, dim3((unsigned)n_tiles), dim3(kExpandThreads), 0, s, comp, c_words, tile_base, info, report);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_index(const u32 *comp, u64 c_words, const u64 *tile_base, const u64 *info, u64 *offsets, u64 capacity,
+                              u32 *ctrl, u64 n_tiles, hipStream_t s) {
+    if (n_tiles) hipLaunchKernelGGL(index_kernel, dim3((unsigned)n_tiles), dim3(kExpandThreads), 0, s, comp, c_words, tile_base, info, offsets, capacity, ctrl);
     return hipGetLastError();
 }
 

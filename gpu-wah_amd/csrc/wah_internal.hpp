@@ -124,6 +124,8 @@ hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s);
 int decode_sums_grid(uint32_t *d_ctrl, hipStream_t s);
 hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t n_tiles, hipStream_t s);
 hipError_t launch_clear(void *p, size_t bytes, hipStream_t s);
+hipError_t launch_build_index(const uint32_t *comp, uint64_t c_words, const uint64_t *tile_base, const uint64_t *info, uint64_t *offsets,
+                              uint64_t capacity, uint32_t *ctrl, uint64_t n_tiles, hipStream_t s);
 hipError_t launch_decode_segments(const SegmentsArgs &a, hipStream_t s);
 hipError_t launch_bitop_segments(const BitopSegArgs &a, hipStream_t s);
 

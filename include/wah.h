@@ -132,6 +132,16 @@ int wah_decompress_segments_device(const uint32_t *d_comp, uint64_t c_words, con
                                    uint64_t first_segment, uint64_t n_segments, uint32_t *d_out, uint64_t out_capacity_words,
                                    void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* The segment index of a stream that came WITHOUT one (written by the reference, read from storage, ...):
+ * d_segment_offsets receives ceil(G / 1024) + 1 entries, exactly what wah_compress_device_indexed() would have
+ * written beside the stream, so that wah_decompress_segments_device / wah_bitop_indexed_device can be used on it from
+ * then on.  One scan of the stream (as wah_decompress_scan_device: d_out_info = [decoded words, groups]) + one pass
+ * that places every word.  A stream in which a fill crosses a 1024-group boundary, or that contains an empty fill,
+ * has no such index: WAH_ERR_STREAM from wah_decompress_status(); too few entries: WAH_ERR_CAPACITY.
+ * Workspace: wah_decompress_workspace_bytes(c_words, 0). */
+int wah_build_index_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_segment_offsets, uint64_t offsets_capacity,
+                           uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* First half of the above only (getCounts + scan): fills d_out_info so a
  * caller that does not know the decoded size can allocate, then call
  * wah_decompress_device (which repeats the scan) or _expand_device. */

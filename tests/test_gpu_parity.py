@@ -700,6 +700,31 @@ def test_decode_segments_rejects_what_is_not_a_segmented_stream(wah, oracle):
     assert np.array_equal(_host(wah.decompress_segments_device(stream, offs, n))[:n], a)
 
 
+def test_build_index_for_streams_that_came_without_one(wah, oracle):
+    """wah_build_index_device: the index of a plain compress() stream == the one the indexed compressor writes; streams
+    that are not segmented (a merged fill across a boundary, an empty fill) have none."""
+    for n in (1, 31, 992, 993, 992 * 3 + 17, 4096 * 31 + 5, 992 * 700):
+        for kind in ("sparse", "dense", "runs"):
+            a = {"sparse": lambda: oracle.gen_uniform(n, 3 + n, 0.01), "dense": lambda: oracle.gen_uniform(n, 4 + n, 0.5),
+                 "runs": lambda: oracle.gen_clustered(n, 5 + n, 3000)}[kind]()
+            stream = _dev(oracle.compress(a))                     # a stream from elsewhere: the CPU oracle
+            offs, groups = wah.build_index_device(stream)
+            _, want = _indexed_stream(wah, _dev(a))
+            assert groups == wah.max_compressed_words(n)
+            assert np.array_equal(offs.cpu().numpy(), want.cpu().numpy()), (n, kind)
+            back = _host(wah.decompress_segments_device(stream, offs, n))
+            assert np.array_equal(back[:n], a), (n, kind)
+    zeros = np.zeros(992 * 5, dtype=np.uint32)
+    merged = wah.merge_fills_device(_dev(oracle.compress(zeros)))  # one fill of 5120 groups
+    assert merged.numel() == 1
+    with pytest.raises(wah.WahError):
+        wah.build_index_device(merged)
+    words = oracle.compress(oracle.gen_clustered(992 * 9, 2, 500)).copy()
+    words[np.flatnonzero(words & 0x80000000)[0]] &= 0xC0000000    # an empty fill
+    with pytest.raises(wah.WahError):
+        wah.build_index_device(_dev(words))
+
+
 def test_decode_segments_full_size(wah):
     """BASELINE size (1 GiB bitmap): index decode == the bitmap, for the three bench distributions."""
     import torch

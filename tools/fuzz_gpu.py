@@ -66,6 +66,10 @@ for seed in range(nc):
             not np.array_equal(T._host(wah.decompress_segments_device(stream, offs, n, first, count)), full[first * 992: (first + count) * 992]):
         bad += 1
         print("INDEX DECODE MISMATCH seed", seed, "n", n, "mode", mode, first, count)
+    bo, bg = wah.build_index_device(T._dev(want))  # the index rebuilt from the bare stream
+    if bg != wah.max_compressed_words(n) or not np.array_equal(bo.cpu().numpy(), offs.cpu().numpy()):
+        bad += 1
+        print("BUILD INDEX MISMATCH seed", seed, "n", n, "mode", mode)
     if n >= 992 and seed % 3 == 0:  # bitwise operations against numpy on the decoded bitmaps
         other = oracle.gen_clustered(n, seed + 7, 900)
         for name, fn in (("and", np.bitwise_and), ("or", np.bitwise_or), ("xor", np.bitwise_xor), ("andnot", lambda x, y: x & ~y)):
