@@ -467,6 +467,45 @@ def test_device_api_is_graph_capturable(wah, oracle):
         assert bool(torch.equal(dec.out[:n], src))
 
 
+def test_indexed_path_is_graph_capturable(wah, oracle):
+    """Indexed compress -> index decode and indexed compress x 2 -> wah_bitop_indexed_device, captured and replayed."""
+    import torch
+
+    n = 992 * 2000
+    srcs = [_dev(oracle.gen_uniform(n, 5, 0.02)), _dev(oracle.gen_clustered(n, 6, 900))]
+    d_a, d_b = srcs[0].clone(), srcs[1].clone()
+    ca, cb = wah.DeviceCompressor(n, indexed=True), wah.DeviceCompressor(n, indexed=True)
+    ca.run(d_a)  # first calls: census, outside the capture
+    cb.run(d_b)
+    seg_ws = torch.empty(int(wah.lib().wah_decompress_segments_workspace_bytes()), dtype=torch.uint8, device="cuda:0")
+    back = torch.empty(n + 1, dtype=torch.int32, device="cuda:0")
+    sc = torch.empty(int(wah.lib().wah_bitop_indexed_scratch_bytes(n)), dtype=torch.uint8, device="cuda:0")
+    res = torch.empty(wah.max_compressed_words(n), dtype=torch.int32, device="cuda:0")
+    res_offs = torch.zeros(n // 992 + 2, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            ca.run(d_a)
+            cb.run(d_b)
+            # the compressed lengths are only known on the device: pass the capacities, the index bounds every segment
+            wah.decompress_segments_device(ca.out, ca.seg_offsets, n, out=back, workspace=seg_ws, check=False)
+            _, count, _ = wah.bitop_indexed_device("xor", ca.out, ca.seg_offsets, cb.out, cb.seg_offsets, n, scratch=sc,
+                                                   out=res, out_offsets=res_offs, check=False)
+    for swap in (False, True, False):
+        x, y = (srcs[1], srcs[0]) if swap else (srcs[0], srcs[1])
+        d_a.copy_(x)
+        d_b.copy_(y)
+        g.replay()
+        torch.cuda.synchronize()
+        ca.status()
+        cb.status()
+        assert bool(torch.equal(back[:n], x))
+        want = oracle.compress(_host(x) ^ _host(y))
+        assert np.array_equal(_host(res[: int(count.item())]), want)
+
+
 def test_misaligned_input_pointer(wah, oracle):
     """A device pointer that is only 4-byte aligned takes the scalar staging path: same words."""
     n = 992 * 50 + 3
