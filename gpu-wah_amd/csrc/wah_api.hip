@@ -247,9 +247,19 @@ bool copy_to_fresh_host(void *host, const void *dev, size_t bytes, bool huge, co
     };
     std::vector<std::thread> helpers;
     helpers.reserve(n_threads);
-    for (unsigned t = 0; t < n_threads; ++t) helpers.emplace_back(fault_in, t);
+    try {
+        for (unsigned t = 0; t < n_threads; ++t) helpers.emplace_back(fault_in, t);
+    } catch (...) { // no threads to be had: whoever did start keeps going, the rest of the chunks are touched here
+    }
+    const unsigned started = (unsigned)helpers.size();
     bool ok = true;
     for (size_t i = 0; i < n_chunks && ok; ++i) {
+        if (i % n_threads >= started) { // the helper that owns this chunk does not exist
+            volatile char *p = static_cast<char *>(host) + i * kChunk;
+            const size_t len = std::min(kChunk, bytes - i * kChunk);
+            for (size_t o = 0; o < len; o += 4096) p[o] = 0;
+            ready[i].store(1, std::memory_order_release);
+        }
         while (!ready[i].load(std::memory_order_acquire)) std::this_thread::yield();
         const size_t len = std::min(kChunk, bytes - i * kChunk);
         ok = hip_ok(hipMemcpy(static_cast<char *>(host) + i * kChunk, static_cast<const char *>(dev) + i * kChunk, len,
