@@ -39,6 +39,7 @@ from .api import (  # noqa: F401
     validate_device,
     bitop_device,
     bitop_indexed_device,
+    bitop_many_indexed_device,
     merge_fills_device,
     StreamReport,
     gen_uniform_device,

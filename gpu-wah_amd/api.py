@@ -55,6 +55,7 @@ ABI_SYMBOLS = {
     "wah_bitop_indexed_scratch_bytes": (_sz, [_u64]),
     "wah_bitop_indexed_device": (_int, [_int, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _sz, _vp]),
     "wah_bitop_indexed_status": (_int, [_vp, _u64, _vp]),
+    "wah_bitop_many_indexed_device": (_int, [_int, _u64, _int, _vp, _vp, _vp, _vp, _u64, _vp, _vp, _vp, _sz, _vp]),
     "wah_gen_uniform_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_gen_clustered_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_copy_device": (_int, [_vp, _vp, _u64, _vp]),
@@ -394,6 +395,38 @@ def bitop_indexed_device(op, d_a, a_offsets, d_b, b_offsets, n_words, scratch=No
     if not check:
         return out, count, out_offsets
     _check(lib().wah_bitop_indexed_status(scratch.data_ptr(), n, sp), "bitop_indexed")
+    return out[: int(count.item())], out_offsets
+
+
+def bitop_many_indexed_device(op, operands, n_words, scratch=None, out=None, out_offsets=None, check=True):
+    """compress(A op B op C ...) for up to 8 (stream, seg_offsets) pairs in one combining pass
+    (wah_bitop_many_indexed_device).  Returns as bitop_indexed_device."""
+    torch = _torch()
+    k = len(operands)
+    for st, _ in operands:
+        _as_words(torch, st)
+    dev = operands[0][0].device
+    n = int(n_words)
+    cap = max_compressed_words(n)
+    n_seg = (cap + 1023) // 1024
+    sc_bytes = int(lib().wah_bitop_indexed_scratch_bytes(n))
+    if scratch is None:
+        scratch = torch.empty(sc_bytes, dtype=torch.uint8, device=dev)
+    if out is None:
+        out = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+    if out_offsets is None:
+        out_offsets = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    streams = (ctypes.c_void_p * k)(*[st.data_ptr() for st, _ in operands])
+    words = (ctypes.c_uint64 * k)(*[st.numel() for st, _ in operands])
+    offsets = (ctypes.c_void_p * k)(*[o.data_ptr() for _, o in operands])
+    sp = _stream_ptr(torch)
+    _check(lib().wah_bitop_many_indexed_device(OPS[op], n, k, streams, words, offsets, out.data_ptr(), out.numel(),
+                                               count.data_ptr(), out_offsets.data_ptr(), scratch.data_ptr(), scratch.numel(), sp),
+           "wah_bitop_many_indexed_device")
+    if not check:
+        return out, count, out_offsets
+    _check(lib().wah_bitop_indexed_status(scratch.data_ptr(), n, sp), "bitop_many_indexed")
     return out[: int(count.item())], out_offsets
 
 

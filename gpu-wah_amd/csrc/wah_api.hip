@@ -824,6 +824,60 @@ int wah_bitop_indexed_device(int op, uint64_t n_words, const uint32_t *d_a, uint
                                 sc + l.ws_c, l.ws_c_bytes, stream);
 }
 
+int wah_bitop_many_indexed_device(int op, uint64_t n_words, int n_operands, const uint32_t *const *d_streams,
+                                  const uint64_t *stream_words, const uint64_t *const *d_offsets, uint32_t *d_out,
+                                  uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_out_offsets, void *d_scratch,
+                                  size_t scratch_bytes, void *stream) {
+    g_err[0] = 0;
+    if (op < WAH_OP_AND || op > WAH_OP_ANDNOT || !d_scratch || (reinterpret_cast<uintptr_t>(d_scratch) & 255u)) {
+        set_err("bad operation or scratch pointer");
+        return WAH_ERR_ARG;
+    }
+    if (n_operands < 1 || n_operands > wah::kMaxBitopOperands || !d_streams || !stream_words || !d_offsets ||
+        n_words >= (1ull << 40)) {
+        set_err("between 1 and 8 operands, each with its stream, length and index");
+        return WAH_ERR_ARG;
+    }
+    wah::BitopManyArgs a = {};
+    for (int j = 0; j < n_operands; ++j) {
+        if (!d_offsets[j] || (stream_words[j] && !d_streams[j]) || stream_words[j] >= (1ull << 40) ||
+            (reinterpret_cast<uintptr_t>(d_streams[j]) & 3u)) {
+            set_err("null or misaligned operand");
+            return WAH_ERR_ARG;
+        }
+        a.comp[j] = d_streams[j];
+        a.c_words[j] = stream_words[j];
+        a.offs[j] = d_offsets[j];
+    }
+    const BitopIndexedLayout l = bitop_indexed_layout(n_words);
+    if (scratch_bytes < l.total) {
+        set_err("scratch too small");
+        return WAH_ERR_WORKSPACE;
+    }
+    char *sc = static_cast<char *>(d_scratch);
+    uint32_t *combined = reinterpret_cast<uint32_t *>(sc + l.bitmap);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint64_t groups = wah_max_compressed_words(n_words);
+    hipError_t e = wah::launch_clear(sc, wah::kCtlWords * sizeof(uint32_t), s);
+    if (e == hipSuccess) {
+        a.g.first_segment = 0;
+        a.g.n_segments = (groups + wah::kSegGroups - 1) / wah::kSegGroups;
+        a.g.groups = groups;
+        a.g.out_words = wah_decoded_words(groups);
+        a.g.out = combined;
+        a.g.ctrl = reinterpret_cast<uint32_t *>(sc);
+        a.n = n_operands;
+        a.op = op;
+        e = wah::launch_bitop_many_segments(a, s);
+    }
+    if (e != hipSuccess) {
+        set_err("combining pass launch", e);
+        return WAH_ERR_HIP;
+    }
+    return compress_device_impl(combined, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, d_out_offsets,
+                                sc + l.ws_c, l.ws_c_bytes, stream);
+}
+
 int wah_bitop_indexed_status(void *d_scratch, uint64_t n_words, void *stream) {
     if (!d_scratch) return WAH_ERR_ARG;
     const int rc = read_status(d_scratch, stream); // the combining pass: operands that are not segmented streams of n_words

@@ -792,6 +792,74 @@ __global__ __launch_bounds__(kSegDecodeWaves * 64) void bitop_segments_kernel(co
     }
 }
 
+// wah_bitop_many_indexed_device: up to kMaxBitopOperands indexed streams, combined left to right (A op B op C ...;
+// ANDNOT: A and not B and not C ...) in one pass: the accumulated segment stays in 16 registers, every further operand
+// goes through the same LDS areas, and its words are loaded while the operand before it is expanded.  (A loop over the
+// operands, not unrolled: eight unrolled copies need 120 registers, 168 bytes of scratch when capped, and are slower.)
+__global__ __launch_bounds__(kSegDecodeWaves * 64, 6) void bitop_many_segments_kernel(const BitopManyArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kSegDecodeWaves][kSegGroups];
+    __shared__ __attribute__((aligned(16))) u32 s_seg[kSegDecodeWaves][kSegGroups];
+    const u32 wave = wave_id(), lane = lane_id();
+    const u64 k = (u64)blockIdx.x * kSegDecodeWaves + wave;
+    if (k >= a.g.n_segments) return;
+    const u64 seg = a.g.first_segment + k;
+    unsigned char *flag = s_flag[wave];
+    u32 *words = s_seg[wave];
+    // minterm masks of `acc op operand` (include/wah.h: WAH_OP_AND 0, OR 1, XOR 2, ANDNOT 3), wave-uniform
+    const u32 k_ab = a.op <= 1 ? ~0u : 0u;
+    const u32 k_a_nb = a.op == 0 ? 0u : ~0u;
+    const u32 k_na_b = a.op == 1 || a.op == 2 ? ~0u : 0u;
+
+    SegmentsArgs cur = a.g; // geometry; stream and index of the operand at hand
+    cur.comp = a.comp[0];
+    cur.c_words = a.c_words[0];
+    SegRange rg = seg_range(cur, seg, uniform64(a.offs[0][seg]), uniform64(a.offs[0][seg + 1]));
+    u32 x0[kSegBatches], x1[kSegBatches];
+    seg_load_words(cur, rg, x0, x1, lane);
+    u32 acc[kSteps];
+    bool ok = true;
+#pragma nounroll
+    for (int j = 0; j < a.n; ++j) {
+        // the next operand's words: in flight during this operand's expansion
+        SegmentsArgs nxt = a.g;
+        SegRange rn = rg;
+        u32 y0[kSegBatches], y1[kSegBatches];
+        const bool more = j + 1 < a.n;
+        if (more) {
+            nxt.comp = a.comp[j + 1];
+            nxt.c_words = a.c_words[j + 1];
+            rn = seg_range(nxt, seg, uniform64(a.offs[j + 1][seg]), uniform64(a.offs[j + 1][seg + 1]));
+            seg_load_words(nxt, rn, y0, y1, lane);
+        }
+        const bool good = seg_mark(rg, x0, x1, flag, words, lane);
+        ok = ok && good;
+        const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
+        const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
+        u32 before = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = 0; s < (int)kSteps; ++s) {
+            const u32 g = seg_group(s, f, before, words, good ? rg.cnt : 1u, rg.nvalid, lane);
+            acc[s] = j == 0 ? g : (acc[s] & g & k_ab) | (acc[s] & ~g & k_a_nb) | (~acc[s] & g & k_na_b);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // words and flags have been read: the areas go to the next operand
+        if (more) {
+#pragma unroll
+            for (int b = 0; b < kSegBatches; ++b) {
+                x0[b] = y0[b];
+                x1[b] = y1[b];
+            }
+            rg = rn;
+        }
+    }
+    if (!ok) {
+        if (lane == 0) atomicOr(a.g.ctrl + kCtlError, kErrStream);
+        return;
+    }
+    const SegStore st = seg_store_setup(a.g.out, a.g.out_words, seg, k, lane);
+#pragma unroll
+    for (int s = 0; s < (int)kSteps; ++s) seg_store(st, s, acc[s] & kOnes31);
+}
+
 } // namespace
 
 int decode_sums_grid(u32 *d_ctrl, hipStream_t s) {
@@ -854,6 +922,13 @@ hipError_t launch_bitop_segments(const BitopSegArgs &a, hipStream_t s) {
     if (a.a.n_segments == 0) return hipSuccess;
     const u64 grid = (a.a.n_segments + kSegDecodeWaves - 1) / kSegDecodeWaves;
     hipLaunchKernelGGL(bitop_segments_kernel, dim3((unsigned)grid), dim3(kSegDecodeWaves * 64), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_bitop_many_segments(const BitopManyArgs &a, hipStream_t s) {
+    if (a.g.n_segments == 0) return hipSuccess;
+    const u64 grid = (a.g.n_segments + kSegDecodeWaves - 1) / kSegDecodeWaves;
+    hipLaunchKernelGGL(bitop_many_segments_kernel, dim3((unsigned)grid), dim3(kSegDecodeWaves * 64), 0, s, a);
     return hipGetLastError();
 }
 

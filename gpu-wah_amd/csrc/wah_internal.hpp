@@ -107,6 +107,17 @@ struct BitopSegArgs {
     int op; // WAH_OP_*
 };
 
+// wah_bitop_many_indexed_device: g = geometry, output and control block (its comp / seg_offsets are not used)
+constexpr int kMaxBitopOperands = 8;
+struct BitopManyArgs {
+    SegmentsArgs g;
+    const uint32_t *comp[kMaxBitopOperands];
+    uint64_t c_words[kMaxBitopOperands];
+    const uint64_t *offs[kMaxBitopOperands];
+    int n;  // operands
+    int op; // WAH_OP_*
+};
+
 // wah_bitop_device: what the operands' decodes left behind, checked on the device before the combining pass
 struct PairCheck {
     const uint64_t *info_a, *info_b; // [decoded words, groups] of the two operands
@@ -128,6 +139,7 @@ hipError_t launch_build_index(const uint32_t *comp, uint64_t c_words, const uint
                               uint64_t capacity, uint32_t *ctrl, uint64_t n_tiles, hipStream_t s);
 hipError_t launch_decode_segments(const SegmentsArgs &a, hipStream_t s);
 hipError_t launch_bitop_segments(const BitopSegArgs &a, hipStream_t s);
+hipError_t launch_bitop_many_segments(const BitopManyArgs &a, hipStream_t s);
 
 // wah_merge_fills_device (after the sums pass): kept-word counts per tile, their scan, scatter, count fix-up
 struct MergeArgs {

@@ -218,6 +218,15 @@ int wah_bitop_indexed_device(int op, uint64_t n_words, const uint32_t *d_a, uint
                              size_t scratch_bytes, void *stream);
 int wah_bitop_indexed_status(void *d_scratch, uint64_t n_words, void *stream);
 
+/* The same for up to 8 operands in ONE combining pass, left to right: A op B op C ... (WAH_OP_ANDNOT: A and not B
+ * and not C ...) -- the conjunction of several predicates of a bitmap index in one go.  d_streams / stream_words /
+ * d_offsets: HOST arrays of n_operands device pointers / lengths / index pointers.  Scratch and status as for
+ * wah_bitop_indexed_device (wah_bitop_indexed_scratch_bytes, wah_bitop_indexed_status). */
+int wah_bitop_many_indexed_device(int op, uint64_t n_words, int n_operands, const uint32_t *const *d_streams,
+                                  const uint64_t *stream_words, const uint64_t *const *d_offsets, uint32_t *d_out,
+                                  uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_out_offsets, void *d_scratch,
+                                  size_t scratch_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Benchmark support: synthetic bitmaps generated in HBM (include/wah_gen.h
  * states the bit-exact definition; replaces tests.cpp:42-64), and a plain

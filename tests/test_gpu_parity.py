@@ -406,6 +406,27 @@ def test_bitops_through_the_segment_indexes(wah, oracle):
         wah.bitop_indexed_device("xor", sa, oa, sa, bad, a.size)
 
 
+def test_many_operand_bitops_through_the_segment_indexes(wah, oracle):
+    """wah_bitop_many_indexed_device: A op B op C ... in one combining pass == numpy on the bitmaps, for 1..8 operands."""
+    fold = {"and": lambda xs: np.bitwise_and.reduce(xs), "or": lambda xs: np.bitwise_or.reduce(xs),
+            "xor": lambda xs: np.bitwise_xor.reduce(xs), "andnot": lambda xs: xs[0] & ~np.bitwise_or.reduce(xs[1:]) if len(xs) > 1 else xs[0]}
+    for n in (992 * 40 + 9, 7, 992 * 257):
+        maps = [oracle.gen_uniform(n, 30 + j, 0.3) if j % 3 == 0 else oracle.gen_clustered(n, 30 + j, 200 + 150 * j) if j % 3 == 1
+                else oracle.gen_uniform(n, 30 + j, 0.9) for j in range(8)]
+        ops = [_indexed_stream(wah, _dev(m)) for m in maps]
+        for k in (1, 2, 3, 5, 8):
+            for name, fn in fold.items():
+                want = oracle.compress(fn(np.stack(maps[:k])).astype(np.uint32))
+                got, offs = wah.bitop_many_indexed_device(name, ops[:k], n)
+                assert got.numel() == want.size and np.array_equal(_host(got), want), (n, k, name)
+    with pytest.raises(wah.WahError):
+        wah.bitop_many_indexed_device("and", ops * 2, n)      # 16 operands
+    bad = ops[2][1].clone()
+    bad[1] += 1
+    with pytest.raises(wah.WahError):
+        wah.bitop_many_indexed_device("or", [ops[0], ops[1], (ops[2][0], bad)], n)
+
+
 def torch_pad(t, n):
     """t extended to n entries by repeating its last one (an index that claims more segments than the stream has)."""
     import torch
