@@ -583,8 +583,10 @@ __global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressAr
         used += count;
         WAH_STAMP(5);
 
-        // stream out whatever has its offset already
-        while (ok && pend != 0u && emit_oldest(gen + 1u, false, lane_v)) {}
+        // (Pending tiles are emitted only when the ring needs the room, above: trying here as well -- "stream out
+        // whatever has its offset already" -- costs an LDS poll per iteration that mostly fails and moves the emission in
+        // front of the next tile's loads; without it the sparse GiB takes 0.349 instead of 0.373 ms, clustered 0.255
+        // instead of 0.270, dense the same.)
 #ifdef WAH_DIAG
         dg_acc[7] += 1;
 #endif
