@@ -72,6 +72,26 @@ def compress_column_matrix(compressor, matrix, wait=True):
     return stream, compressor.seg_offsets[:: segs][: columns + 1]
 
 
+def compress_column_ranges(compressor, flat, lengths, wait=True):
+    """Columns of DIFFERENT lengths (each a multiple of 992 words) stored back to back in `flat`: still one launch.
+    Returns (stream, column_offsets) like compress_column_matrix: column c is stream[column_offsets[c] :
+    column_offsets[c + 1]], bit-identical to compressing it alone (F4: a fill never crosses a 992-word segment)."""
+    import torch
+
+    if any(n % SEGMENT_WORDS for n in lengths) or sum(lengths) != flat.numel() or not flat.is_contiguous():
+        raise ValueError("column lengths must be multiples of 992 words and add up to the buffer")
+    if compressor.seg_offsets is None:
+        raise ValueError("needs DeviceCompressor(..., indexed=True)")
+    compressor.run(flat)
+    if not wait:
+        return None, None
+    stream = compressor.result()
+    first_segment = [0]
+    for n in lengths:
+        first_segment.append(first_segment[-1] + n // SEGMENT_WORDS)
+    return stream, compressor.seg_offsets[torch.tensor(first_segment, device=compressor.seg_offsets.device)]
+
+
 def compress_columns(compressor, columns):
     """Enqueue one compress pass per column on the current stream; returns the list of compressed sizes
     (device tensors, read them after synchronising).  The compressor's output buffer is reused, so callers

@@ -799,6 +799,28 @@ def test_decode_segments_full_size(wah):
         del stream, offs, back, col
 
 
+def test_ragged_columns_one_launch(wah, oracle):
+    """Columns of different lengths (multiples of 992 words) back to back in one buffer: one launch, every column's
+    stream bit-identical to compressing it alone; one column decoded through the index."""
+    import torch
+
+    lengths = [992 * 3, 992 * 700, 992, 992 * 41, 992 * 256]
+    cols = [oracle.gen_uniform(n, 60 + i, (0.01, 0.5, 0.2)[i % 3]) if i % 2 == 0 else oracle.gen_clustered(n, 60 + i, 700)
+            for i, n in enumerate(lengths)]
+    flat = _dev(np.concatenate(cols))
+    comp = wah.DeviceCompressor(flat.numel(), indexed=True)
+    stream, offs = wah.columns.compress_column_ranges(comp, flat, lengths)
+    offs = offs.cpu().numpy()
+    assert offs[0] == 0 and offs[-1] == stream.numel() and len(offs) == len(lengths) + 1
+    for c, col in enumerate(cols):
+        assert np.array_equal(_host(stream[offs[c]: offs[c + 1]]), oracle.compress(col)), c
+    first = sum(lengths[:3]) // 992
+    back = wah.decompress_segments_device(stream, comp.seg_offsets, flat.numel(), first, lengths[3] // 992)
+    assert np.array_equal(_host(back), cols[3])
+    with pytest.raises(ValueError):
+        wah.columns.compress_column_ranges(comp, flat, [992 * 3 + 1] + lengths[1:])
+
+
 # ---------------------------------------------------------------- the reference's own test code
 def test_reference_tests_cpp_against_hip_library(wah):
     """oracle/_ref/ref_tests_hip = /root/reference/tests.cpp compiled in the authoring container and linked
