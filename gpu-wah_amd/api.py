@@ -36,6 +36,7 @@ ABI_SYMBOLS = {
     "wah_decoded_words": (_u64, [_u64]),
     "wah_compress_workspace_bytes": (_sz, [_u64]),
     "wah_decompress_workspace_bytes": (_sz, [_u64, _u64]),
+    "wah_workspace_init_device": (_int, [_vp, _sz, _vp]),
     "wah_compress_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_compress_device_indexed": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _sz, _vp]),
     "wah_compress_status": (_int, [_vp, _vp]),
@@ -209,7 +210,8 @@ class DeviceCompressor:
         self.n_words = int(n_words)
         self.capacity = max_compressed_words(self.n_words)
         self.ws_bytes = int(lib().wah_compress_workspace_bytes(self.n_words))
-        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        # zeroed once (include/wah.h: wah_workspace_init_device); the kernel keeps it up from then on
+        self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=device)
         self.out = torch.empty(max(self.capacity, 1), dtype=torch.int32, device=device)
         self.count = torch.zeros(1, dtype=torch.int64, device=device)
         n_seg = (self.capacity + 1023) // 1024

@@ -38,20 +38,19 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 struct CompressLayout {
     uint64_t n_groups, n_segments, n_tiles;
-    size_t ctrl_off, desc_off, block_off, total;
+    size_t ctrl_off, desc_off, total;
 };
 
+// [control block][scan area: one block of kScanBlockWords per 64 x 256 tiles, + the block a full last superrow publishes into]
 CompressLayout compress_layout(uint64_t n_words) {
     CompressLayout l;
     l.n_groups = wah_max_compressed_words(n_words);
     l.n_segments = ceil_div(l.n_groups, wah::kSegGroups);
-    l.n_tiles = ceil_div(l.n_segments, (uint64_t)wah::compress_workers());
+    l.n_tiles = ceil_div(l.n_segments, (uint64_t)(wah::kCompressTileWaves * wah::kCompressWaveSegs));
+    const uint64_t blocks = l.n_tiles / wah::kScanBlockTiles + 1;
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
-    // generation rows: rows of round_up(G, 4) granules for G resident workgroups (G is only known after the
-    // census): at most n_tiles + 3 * generations + 3 <= 4 * n_tiles + 8 granules
-    l.block_off = l.desc_off;
-    l.total = round256(l.desc_off + (4 * l.n_tiles + 8) * sizeof(uint32_t));
+    l.total = round256(l.desc_off + blocks * wah::kScanBlockWords * sizeof(uint32_t));
     return l;
 }
 
@@ -85,6 +84,10 @@ int read_status(void *d_workspace, void *stream, const uint64_t *d_vals = nullpt
     if (e != hipSuccess) {
         set_err("status read-back", e);
         return WAH_ERR_HIP;
+    }
+    if (err & wah::kErrWorkspace) {
+        set_err("compress workspace was not initialised (wah_workspace_init_device)");
+        return WAH_ERR_WORKSPACE;
     }
     if (err & wah::kErrTimeout) {
         set_err("in-kernel bounded wait expired");
@@ -148,12 +151,14 @@ struct HostCall {
         if (!keep) cache.release_locked();
     }
     // slot: which buffer of the set; a kept buffer that is large enough is handed out again as it is
-    bool alloc(int slot, void **p, size_t bytes, const char *what) {
+    bool alloc(int slot, void **p, size_t bytes, const char *what, bool *fresh = nullptr) {
         if (bytes == 0) bytes = 16;
+        if (fresh) *fresh = false;
         if (cache.buf[slot] && cache.cap[slot] >= bytes) {
             *p = cache.buf[slot];
             return true;
         }
+        if (fresh) *fresh = true;
         if (cache.buf[slot]) (void)hipFree(cache.buf[slot]);
         cache.buf[slot] = nullptr;
         cache.cap[slot] = 0;
@@ -272,14 +277,6 @@ bool copy_to_fresh_host(void *host, const void *dev, size_t bytes, bool huge, co
 
 } // namespace
 
-int wah::compress_workers() {
-    static const int w = [] {
-        const char *e = std::getenv("WAH_WORKERS");
-        return (e && std::atoi(e) == 7) ? 7 : wah::kCompressWavesDefault;
-    }();
-    return w;
-}
-
 extern "C" {
 
 const char *wah_last_error(void) { return g_err; }
@@ -300,9 +297,11 @@ size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_wo
     return decode_layout(c_words).total;
 }
 
+// clear_first: the caller's workspace is scratch of unknown content (the bitop paths): zero all of it in front of the
+// launch, which makes it a fresh workspace every time -- and keep whatever error an upstream pass leaves in it.
 static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int op, const wah::PairCheck *check, uint64_t n_words,
                                 uint32_t *d_out, uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_segment_offsets,
-                                void *d_workspace, size_t workspace_bytes, void *stream) {
+                                void *d_workspace, size_t workspace_bytes, void *stream, bool clear_first) {
     g_err[0] = 0;
     if (!d_out_words || !d_workspace || (n_words && (!d_in || !d_out))) {
         set_err("null pointer");
@@ -319,26 +318,20 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(d_workspace);
-    // first call on a device: residency census of the compress kernel (one extra launch + sync, then cached)
-    const int workers = wah::compress_workers();
-    const int resident = n_words ? wah::compress_grid(workers, reinterpret_cast<uint32_t *>(ws), s) : 1;
-    if (resident < 1) {
-        set_err("residency census failed", hipGetLastError());
-        return WAH_ERR_HIP;
-    }
-    const uint64_t grid64 = (uint64_t)resident < l.n_tiles ? (uint64_t)resident : (l.n_tiles ? l.n_tiles : 1);
-    const uint64_t generations = (l.n_tiles + grid64 - 1) / grid64;
-    const size_t used = round256(l.desc_off + (generations * ((grid64 + 3) & ~3ull) + 8) * sizeof(uint32_t));
-    hipError_t e = wah::launch_clear(ws, used < l.total ? used : l.total, s);
-    if (e != hipSuccess) {
-        set_err("clearing the workspace", e);
-        return WAH_ERR_HIP;
+    hipError_t e = hipSuccess;
+    if (clear_first) {
+        e = wah::launch_clear(ws, l.total, s);
+        if (e != hipSuccess) {
+            set_err("clearing the workspace", e);
+            return WAH_ERR_HIP;
+        }
     }
     if (n_words == 0) {
         e = wah::launch_clear(d_out_words, sizeof(uint64_t), s);
         if (e == hipSuccess && d_segment_offsets) e = wah::launch_clear(d_segment_offsets, sizeof(uint64_t), s);
+        if (e == hipSuccess && !clear_first) e = wah::launch_clear(ws + wah::kCtlError * sizeof(uint32_t), sizeof(uint32_t), s);
         if (e != hipSuccess) {
-            set_err("clearing the workspace", e);
+            set_err("clearing the outputs", e);
             return WAH_ERR_HIP;
         }
         return WAH_OK;
@@ -358,22 +351,41 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     a.seg_offsets = d_segment_offsets;
     a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
     a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
-    a.census = 0;
+    a.scan_words = (l.total - l.desc_off) / sizeof(uint32_t);
+    a.keep_error = clear_first ? 1 : 0;
+    {
+        static const uint32_t tune = [] {
+            const char *e = std::getenv("WAH_TUNE");
+            return e ? (uint32_t)std::strtoul(e, nullptr, 0) : 0u;
+        }();
+        a.tune = tune;
+    }
     a.in2 = d_in2;
     a.op = (uint32_t)op;
-    const int grid = (int)grid64;
     if (d_in2) {
-        if (!a.fast_segments || !aligned16(d_in2) || workers != 15) {
+        if (!a.fast_segments || !aligned16(d_in2)) {
             set_err("pair mode needs 16-byte aligned bitmaps");
             return WAH_ERR_ARG;
         }
         if (check) e = wah::launch_bitop_check(check->info_a, check->info_b, check->ctrl_a, check->ctrl_b, check->groups, a.ctrl, s);
-        if (e == hipSuccess) e = wah::launch_compress_pair(a, grid, s);
-    } else {
-        e = wah::launch_compress(workers, a, grid, s);
     }
+    if (e == hipSuccess) e = wah::launch_compress(a, s);
     if (e != hipSuccess) {
         set_err("compress kernel launch", e);
+        return WAH_ERR_HIP;
+    }
+    return WAH_OK;
+}
+
+int wah_workspace_init_device(void *d_workspace, size_t workspace_bytes, void *stream) {
+    g_err[0] = 0;
+    if (!d_workspace || (reinterpret_cast<uintptr_t>(d_workspace) & 255u)) {
+        set_err("null or misaligned workspace");
+        return WAH_ERR_ARG;
+    }
+    const hipError_t e = wah::launch_clear(d_workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        set_err("clearing the workspace", e);
         return WAH_ERR_HIP;
     }
     return WAH_OK;
@@ -383,7 +395,7 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
                                 uint64_t *d_out_words, uint64_t *d_segment_offsets, void *d_workspace,
                                 size_t workspace_bytes, void *stream) {
     return compress_device_impl(d_in, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, d_segment_offsets,
-                                d_workspace, workspace_bytes, stream);
+                                d_workspace, workspace_bytes, stream, false);
 }
 
 int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
@@ -665,7 +677,7 @@ int wah_bitop_device(int op, uint64_t n_words, const uint32_t *d_a, uint64_t a_w
     check.ctrl_b = reinterpret_cast<const uint32_t *>(sc + l.ws_b);
     check.groups = wah_max_compressed_words(n_words);
     return compress_device_impl(bm_a, bm_b, op, &check, n_words, d_out, out_capacity_words, d_out_words, nullptr, sc + l.ws_c,
-                                l.ws_c_bytes, stream);
+                                l.ws_c_bytes, stream, true);
 }
 
 int wah_bitop_status(void *d_scratch, uint64_t n_words, uint64_t a_words, uint64_t b_words, void *stream) {
@@ -821,7 +833,7 @@ int wah_bitop_indexed_device(int op, uint64_t n_words, const uint32_t *d_a, uint
         return WAH_ERR_HIP;
     }
     return compress_device_impl(combined, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, d_out_offsets,
-                                sc + l.ws_c, l.ws_c_bytes, stream);
+                                sc + l.ws_c, l.ws_c_bytes, stream, true);
 }
 
 int wah_bitop_many_indexed_device(int op, uint64_t n_words, int n_operands, const uint32_t *const *d_streams,
@@ -875,7 +887,7 @@ int wah_bitop_many_indexed_device(int op, uint64_t n_words, int n_operands, cons
         return WAH_ERR_HIP;
     }
     return compress_device_impl(combined, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, d_out_offsets,
-                                sc + l.ws_c, l.ws_c_bytes, stream);
+                                sc + l.ws_c, l.ws_c_bytes, stream, true);
 }
 
 int wah_bitop_indexed_status(void *d_scratch, uint64_t n_words, void *stream) {
@@ -910,7 +922,10 @@ uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *ou
     void *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr, *d_cnt = nullptr;
     if (!hc.alloc(0, &d_in, n_words * sizeof(uint32_t), "space for the data")) return nullptr;
     if (!hc.alloc(1, &d_out, cap * sizeof(uint32_t), "space for the compressed output")) return nullptr;
-    if (!hc.alloc(2, &d_ws, ws_bytes, "workspace")) return nullptr;
+    bool fresh_ws = false;
+    if (!hc.alloc(2, &d_ws, ws_bytes, "workspace", &fresh_ws)) return nullptr;
+    // the compress workspace is zeroed once; from then on the kernel keeps it up itself (launch epochs)
+    if (fresh_ws && wah_workspace_init_device(d_ws, ws_bytes, nullptr) != WAH_OK) return nullptr;
     if (!hc.alloc(3, &d_cnt, sizeof(uint64_t), "output size")) return nullptr;
     if (n_words && !hip_ok(hipMemcpy(d_in, data_host, n_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
         return nullptr;

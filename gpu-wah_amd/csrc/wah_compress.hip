@@ -3,21 +3,20 @@
 //
 // What the reference does in five kernels, two thrust scans and four blocking 8-byte D2H copies
 // (compress.cu:129-166, decompress.cu:66-115, kernels.cu), is done here in
-//   compress   : ONE persistent kernel            (reads 4N, writes 4C, nothing else)
-//   decompress : streaming sums kernel + expand   (reads 4C twice, writes 4N')
+//   compress   : ONE kernel of short-lived workgroups  (reads 4N, writes 4C, nothing else)
+//   decompress : streaming sums kernel + expand        (reads 4C twice, writes 4N')
 // built on these CDNA4 idioms:
 //   * a wavefront (64 lanes) owns a whole 1024-group segment; its 992 words are staged once in wave-private LDS
 //     with 16-byte coalesced loads and re-read as 31-bit groups by a funnel shift (v_alignbit) -- the regroup of
 //     kernels.cu:72-79 without idle lanes and without the shift-by-32;
 //   * zero/ones classification produces 64-lane masks straight from v_cmp, "same as the next group" is one DPP
 //     compare, so run detection, run lengths and the cross-warp merge (kernels.cu:126-229) collapse into a couple
-//     of scalar mask operations per 64 groups plus one v_mbcnt rank per lane;
-//   * run-end words are compacted in LDS and leave the chip as dense 256-byte stores;
-//   * output offsets come from a one-hop "generation scan" over 4-byte {valid,count} granules written and polled
-//     with agent-scope relaxed atomics (correct across the 8 non-coherent XCD L2s), instead of
-//     thrust::exclusive_scan + moveData (compress.cu:133-166, kernels.cu:273-280);
-//   * tiles are assigned round robin to the workgroups in arrival order, the grid is sized from a residency census
-//     of the kernel itself, and every wait is bounded: a lost workgroup ends in WAH_ERR_TIMEOUT, never in a hang.
+//     of mask operations per 64 groups plus one v_mbcnt rank per lane;
+//   * run-end words are compacted in LDS, turned into final words in REGISTERS (where they wait for the tile's output
+//     offset without holding LDS bandwidth) and leave the chip as dense 256-byte stores;
+//   * output offsets come from a one-hop "row scan" over 4-byte {epoch, count} granules written and read with
+//     agent-scope accesses (correct across the 8 non-coherent XCD L2s), instead of thrust::exclusive_scan + moveData
+//     (compress.cu:133-166, kernels.cu:273-280); nothing is persistent and nothing is cleared between launches.
 #include "wah_device.hpp"
 
 namespace wah {
@@ -48,30 +47,33 @@ struct Prefetch {
     u32x4 v[4];
 };
 
-// issue the four coalesced 16-byte loads of one segment (3968 B = 248 x 16 B; lanes 56..63 of the fourth load and
-// everything past the end of the bitmap read as zero)
-__device__ __forceinline__ void prefetch_segment(const CompressArgs &a, u32 seg, u32 lane, Prefetch &p) {
-    // whole segments: 3968 bytes; the (one) partial segment at the end of the bitmap: what is left of it
-    const u32 bytes = seg < a.full_segments ? kSegWords * 4u : a.tail_bytes;
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.in + (u64)seg * kSegWords, bytes);
-    const u32 off = lane * 16u;
-    p.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-    p.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 1024u, 0, 0);
-    p.v[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 2048u, 0, 0);
-    p.v[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 3072u, 0, 0);
+// one 16-byte load; an input that is only 4-byte aligned takes four dword loads into the same registers
+template <bool kAligned>
+__device__ __forceinline__ u32x4 load16(__amdgpu_buffer_rsrc_t rsrc, u32 off) {
+    if (kAligned) return __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    u32x4 v;
+    v.x = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0);
+    v.y = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 4u, 0, 0);
+    v.z = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 8u, 0, 0);
+    v.w = __builtin_amdgcn_raw_buffer_load_b32(rsrc, off + 12u, 0, 0);
+    return v;
 }
 
-// pair mode: the same four loads from the second bitmap
-__device__ __forceinline__ void prefetch_segment2(const CompressArgs &a, u32 seg, u32 lane, Prefetch &p) {
+// issue the four coalesced 16-byte loads of one segment (3968 B = 248 x 16 B; lanes 56..63 of the fourth load and
+// everything past the end of the bitmap read as zero: the descriptor's bounds do the zero padding of the tail, F5)
+template <bool kAligned>
+__device__ __forceinline__ void prefetch_segment(const u32 *in, const CompressArgs &a, u32 seg, u32 lane, Prefetch &p) {
+    // whole segments: 3968 bytes; the (one) partial segment at the end of the bitmap: what is left of it
     const u32 bytes = seg < a.full_segments ? kSegWords * 4u : a.tail_bytes;
-    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.in2 + (u64)seg * kSegWords, bytes);
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(in + (u64)seg * kSegWords, bytes);
     const u32 off = lane * 16u;
-    p.v[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-    p.v[1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 1024u, 0, 0);
-    p.v[2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 2048u, 0, 0);
-    p.v[3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 3072u, 0, 0);
+    p.v[0] = load16<kAligned>(rsrc, off);
+    p.v[1] = load16<kAligned>(rsrc, off + 1024u);
+    p.v[2] = load16<kAligned>(rsrc, off + 2048u);
+    p.v[3] = load16<kAligned>(rsrc, off + 3072u);
 }
-// ... and the word-by-word combination (include/wah.h: WAH_OP_*); words behind the bitmap stay zero for every op
+
+// pair mode: the word-by-word combination (include/wah.h: WAH_OP_*); words behind the bitmap stay zero for every op
 __device__ __forceinline__ void combine_pair(Prefetch &p, const Prefetch &q, u32 op) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -93,42 +95,25 @@ __device__ __forceinline__ void stage_prefetched(const Prefetch &p, u32 *lds, u3
     dst[lane + 192] = p.v[3];
 }
 
-// input that is only 4-byte aligned: bounds-checked scalar staging, zero padded (F5)
-__device__ __forceinline__ void stage_slow(const CompressArgs &a, u32 seg, u32 *lds, u32 lane) {
-    const u64 w0 = (u64)seg * kSegWords;
-    const u64 left = a.n_words - w0;
-    const u32 have = left < kSegWords ? (u32)left : kSegWords; // wave-uniform
-    const u32 *src = a.in + w0;
-    for (u32 i = lane; i < kSegWords + 64; i += 64)
-        if (i <= kSegWords) lds[i] = i < have ? src[i] : 0u;
-}
-
 // Classify + run detect + compact one staged segment (wave-private LDS), returns the number of words produced.
 //   classify  (kernels.cu:93-112): group = funnel shift of two staged words; zero / ones kinds by v_cmp, whose
 //             result IS the 64-lane mask.
 //   run ends  (kernels.cu:126-141 + the cross-warp merge of :188-229): a group does NOT end a run iff it is a
 //             fill and the next group of the segment has the same value.  "Same as next" is one DPP compare
-//             against the neighbouring lane (lane 63 is patched with lane 0 of the following step), so the
-//             scalar side is three mask operations per 64 groups.  The group after the last one never matches,
-//             so every segment closes its last run (tests.cpp:166-172).
-//   compact   : step s-1 is finished once step s is classified; its run-end words go to LDS at rank = running
-//             count + mbcnt, written over staged words that every later step has already left behind
-//             (rank < 64 s <= 62 (s+1), the lowest word still to be read), with the group position beside it
-//             (fill lengths are position differences, see the emit loop).
-// kFull = all 1024 groups exist (every segment but possibly the last one of the bitmap).
-// v_bcnt_u32_b32: acc + popcount(mask half).  Spelled out because the compiler would do a uniform popcount on the
-// scalar unit and then needs a scalar add, a v_mov back and hazard nops around them: keeping the wave-uniform running
-// count in a vector register makes the whole step a straight run of vector instructions (the scalar unit is shared
-// by the four SIMDs of a CU and already carries the loop control and hand-off code).
-__device__ __forceinline__ u32 add_popcount(u32 acc, u64 mask) {
-    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "s"((u32)mask));
-    asm("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc) : "s"((u32)(mask >> 32)));
-    return acc;
-}
+//             against the neighbouring lane (lane 63 is patched with lane 0 of the following step).  The group
+//             after the last one never matches, so every segment closes its last run (tests.cpp:166-172).
+//   compact   : run-end words go to LDS at rank = running count + mbcnt, written over the staged words (all of
+//             which are in registers by then), with the group position beside it (fill lengths are position
+//             differences, see final_words_to_regs).
+// The 16 steps are one generated, hand-scheduled block (csrc/classify_block.inc, tools/gen_classify_block.py):
+// 13.5 vector + 2 LDS instructions per step, software-pipelined by one step so that no hazard needs a wait state.
+// The bitmap's last segment may be short (F5): the groups that do not exist are replaced by a literal -- literals
+// never merge, so the last real group closes its run and each of them becomes one entry BEHIND the real ones, which
+// is simply not counted.
+constexpr u32 kAbsentGroup = 0x2AAAAAAAu;
 
-template <bool kFull>
-__device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigned short *pos, u32 r, u32 lane_v,
-                                                u32 nvalid, bool long_fills, bool &any_fill) {
+__device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigned short *pos, u32 r, u32 lane_v, u32 nvalid,
+                                                bool &any_fill) {
     // phase 1: all 16 LDS reads, then the funnel shifts: every staged word is in registers before the first
     // compacted word overwrites the staging buffer
     u32 x[kSteps + 1];
@@ -139,6 +124,10 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
         x[s] = __builtin_amdgcn_alignbit(hi, lo, r) & kOnes31;
     }
     x[kSteps] = 0xFFFFFFFFu; // "group after the last one": a value no 31-bit group can equal
+    if (nvalid != kSegGroups) {
+#pragma unroll
+        for (int s = 0; s < (int)kSteps; ++s) x[s] = 64u * s + lane_v < nvalid ? x[s] : kAbsentGroup;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     // phase 2: one straight-line block of vector instructions per step.
@@ -147,512 +136,441 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
     //   z      : (x ^ next) | ((x + 1) & 0x7FFFFFFE) is zero  <=>  x is 0 or 0x7FFFFFFF AND the next group equals it
     //            <=>  the group does NOT end a run (kernels.cu:93-141 and the merge of :188-229 in three operations)
     //   ends   : v_cmp_ne z, 0 -- the 64-lane mask comes out of the compare itself
-    //   rank   : v_mbcnt pair seeded with the running count; count += v_bcnt pair
-    //   write  : every lane stores; lanes that end no run store to a dump slot (cheaper than masking EXEC, which
-    //            is scalar work)
+    //   rank   : v_mbcnt pair seeded with the running count (kept in a VECTOR register: no scalar work); count += v_bcnt pair
+    //   write  : every lane stores; lanes that end no run store to a dump slot (cheaper than masking EXEC)
     u32 count_v = 0;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(count_v)); // a VECTOR zero: keeps the running count off the scalar unit
-    u32 min_t = 0xFFFFFFFFu;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(count_v));
     // LDS byte addresses: value k at vbase + 4 k, its position at pbase + 2 k; k = kStageWords is the dump slot
     const u32 vbase = (u32)(uintptr_t)(lds_u32_ptr)lds;
     const u32 pbase = (u32)(uintptr_t)(lds_u16_ptr)pos + 2u;
     u32 dump_slot;
     asm volatile("v_mov_b32 %0, 0x400" : "=v"(dump_slot)); // kStageWords, in a vector register (v_cndmask cannot take a literal)
     static_assert(kStageWords == 0x400, "dump slot literal");
-    if (kFull) {
-        // Hand-scheduled block for the 16 steps (csrc/classify_block.inc, generated by tools/gen_classify_block.py):
-        // 13.5 vector + 2 LDS instructions per step, software-pipelined by one step so that no hazard needs a wait
-        // state (a DPP source or a v_cmp mask read as data must be two instructions old; the compiler pads with
-        // s_nop, also around every asm statement).  The kernel is bound by vector issue, so
-        // every instruction here is ~0.25 % of its run time.
-        u32 na, ta, nb, tb, ps;
-        const u32 lane2 = lane_v * 0x10001u; // the lane id in both halves: position words are built two at a time
-        // two schedules of the same block: `long_fills` (the wave's previous segment compressed to a few words) takes
-        // the one in which a step without any run end branches over the ranking and the stores
-#define WAH_CLASSIFY_OPERANDS                                                                                                  \
-    : [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)                      \
-    : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]), [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]), [x12] "v"(x[12]), [x13] "v"(x[13]), [x14] "v"(x[14]), [x15] "v"(x[15]), [x16] "v"(x[16]),                                                                                                                  \
-      [ln2] "v"(lane2), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)                                                  \
-    : "vcc", "memory"
-        if (long_fills) {
-            asm volatile(
-#include "classify_block_skip.inc"
-                WAH_CLASSIFY_OPERANDS);
-        } else {
-            asm volatile(
+    u32 na, ta, nb, tb, ps;
+    const u32 lane2 = lane_v * 0x10001u; // the lane id in both halves: position words are built two at a time
+    asm volatile(
 #include "classify_block.inc"
-                WAH_CLASSIFY_OPERANDS);
-        }
-#undef WAH_CLASSIFY_OPERANDS
-        const u32 count = uniform32(count_v);
-        // Some emitted word is a fill iff some group is one.  Fewer words than groups: certainly.  As many words as
-        // groups (incompressible data): only fills of length 1 are possible, look for an all-zero / all-one group.
-        any_fill = true;
-        if (count == kSegGroups) {
-            u32 lo = x[0], hi = x[0];
+        : [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)
+        : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]),
+          [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]), [x12] "v"(x[12]), [x13] "v"(x[13]), [x14] "v"(x[14]),
+          [x15] "v"(x[15]), [x16] "v"(x[16]), [ln2] "v"(lane2), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)
+        : "vcc", "memory");
+    u32 count = uniform32(count_v);
+    // Some emitted word is a fill iff some group is one.  Fewer words than groups: certainly.  As many words as
+    // groups (incompressible data): only fills of length 1 are possible, look for an all-zero / all-one group.
+    any_fill = true;
+    if (count == kSegGroups && nvalid == kSegGroups) {
+        u32 lo = x[0], hi = x[0];
 #pragma unroll
-            for (int s = 1; s < (int)kSteps; s += 2) {
-                lo = s + 1 < (int)kSteps ? min(lo, min(x[s], x[s + 1])) : min(lo, x[s]);
-                hi = s + 1 < (int)kSteps ? max(hi, max(x[s], x[s + 1])) : max(hi, x[s]);
-            }
-            any_fill = __ballot(lo == 0u || hi == kOnes31) != 0;
+        for (int s = 1; s < (int)kSteps; s += 2) {
+            lo = s + 1 < (int)kSteps ? min(lo, min(x[s], x[s + 1])) : min(lo, x[s]);
+            hi = s + 1 < (int)kSteps ? max(hi, max(x[s], x[s + 1])) : max(hi, x[s]);
         }
-        return count;
+        any_fill = __ballot(lo == 0u || hi == kOnes31) != 0;
     }
-#pragma unroll
-    for (int s = 0; s < (int)kSteps; ++s) {
-        const u32 carry = (u32)__builtin_amdgcn_mov_dpp((int)x[s + 1], 0x134 /* wave_rol:1 */, 0xf, 0xf, true);
-        const u32 nxt = __builtin_amdgcn_update_dpp(carry, x[s], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-        const u32 t = (x[s] + 1u) & 0x7FFFFFFEu; // zero <=> x is all zeros or all ones
-        const u32 z = __builtin_amdgcn_bitop3_b32(x[s], nxt, t, 0xbe); // (x ^ next) | t
-        u64 e = __ballot(z != 0u);
-        const int rem = (int)nvalid - 64 * s;
-        const u64 valid = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-        const u64 last = (rem >= 1 && rem <= 64) ? (1ull << (rem - 1)) : 0ull; // the last existing group closes its run
-        e = (e | last) & valid;
-        if (rem > 0) min_t = min(min_t, (lane_v < (u32)rem) ? t : 0xFFFFFFFFu);
-        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(e >> 32), __builtin_amdgcn_mbcnt_lo((u32)e, count_v));
-        const u32 slot = __builtin_amdgcn_inverse_ballot_w64(e) ? rank : kStageWords;
-        *(lds_u32_ptr)(uintptr_t)(vbase + (slot << 2)) = x[s];
-        *(lds_u16_ptr)(uintptr_t)(pbase + (slot << 1)) = (unsigned short)(64 * s + (int)lane_v);
-        count_v = add_popcount(count_v, e);
-    }
-    any_fill = __ballot(min_t == 0u) != 0; // some group is a fill, so some emitted word is one
-    return uniform32(count_v);
+    return count - (kSegGroups - nvalid);
 }
 
-constexpr u32 kDepth = 8;      // generations a workgroup keeps bookkeeping for (power of two)
-constexpr u32 kMaxPending = 4; // finished tiles a worker may hold in LDS while their offsets resolve (< kDepth - 2)
+// ===========================================================================
+// compress_tile_kernel
+//
+// Workgroup = one TILE of kTileWaves consecutive segments, one short-lived wavefront per segment, tile = blockIdx.x.
+//   every wave : 4 x 16-byte loads of its segment -> private 4 KiB LDS stage -> classify + compact in place
+//                (classify_compact) -> count to LDS -> barrier -> [wave 0: row scan] -> barrier -> final words
+//                (fill length = distance between consecutive run ends) straight from LDS to their place in the
+//                output with dense 256-byte stores (kernels.cu:244-259 + moveData, kernels.cu:273-280).
+//   wave 0     : additionally resolves the tile's output offset with the ROW SCAN below.  Its granule loads are
+//                issued BEFORE it classifies its own segment, so they come back about when the count is known.
+// Nothing is persistent: no residency census, no arrival tickets, nothing to clear between launches, and a wave
+// that waits at the barrier issues no instructions (the SIMDs of this kernel are bound by instruction issue).
+//
+// Row scan (replaces thrust::exclusive_scan + the two blocking 8-byte reads of compress.cu:133-157).
+//   granule[t]           u32 {epoch:17, words:15} of tile t, published as soon as the tile's words are counted
+//   slot[s][0]           u64 {epoch:17, words:47}: words in front of superrow s  (superrow = kSuperRows rows)
+//   slot[s][1 + k]       u64 {epoch:17, words:47}: words of row k of superrow s  (row = kRowTiles tiles)
+// (scan area = one block per superrow: its 64 x 256 granules, then its 65 slots -- every entry has the same address and
+//  the same meaning whatever the size of the bitmap, so a workspace can serve bitmaps of different sizes in turn)
+// Tile (row r, index i) adds up, in ONE round trip of three loads per lane:
+//   granule[r][0 .. i)  +  granule[r-1][0 .. 256)  +  slot[s][1 ..] of rows s0 .. r-2  +  slot[s][0]
+// The last tile of a row publishes the row's slot as soon as its own row is complete (no dependency on anything
+// older), the last tile of a superrow publishes the next superrow's slot[.][0].  So every dependency is "published
+// by a tile with a smaller blockIdx" and at most one hop old; rows r-2 and older had >= one whole row of time.
+// Order: workgroups are dispatched in blockIdx order (round robin over the XCDs, in order inside each), so the
+// lowest unfinished tile is always running or next in line on its XCD; every wait is bounded all the same
+// (WAH_ERR_TIMEOUT, never a hang).
+// Epochs: the workspace is never cleared.  Every launch stamps what it publishes with the launch epoch kept in the
+// control block (read by every workgroup at its start, advanced by the LAST tile once its scan is complete -- by
+// then every other tile has published, hence started).  A zeroed workspace is epoch 0 = "nothing valid".  When
+// the 17-bit epoch is used up, the next launch has tile 0 clear the scan area while the others wait for it.
+// ===========================================================================
+constexpr u32 kTileWaves = (u32)kCompressTileWaves;
+constexpr u32 kRowTiles = 256;             // granules per row: one 16-byte load per lane
+constexpr u32 kSuperRows = 64;             // rows per superrow: one 8-byte load per lane
+constexpr u32 kWaveSegs = (u32)kCompressWaveSegs;
+constexpr u32 kCountBits = 15;             // words of a tile <= 8 * 2 * 1024
+constexpr u32 kCountMask = (1u << kCountBits) - 1u;
+constexpr u32 kSlotShift = 47;             // u64 slots: value in the low 47 bits
+constexpr u64 kSlotMask = (1ull << kSlotShift) - 1ull;
+static_assert(kTileWaves * kWaveSegs * kSegGroups <= kCountMask, "tile count must fit the granule");
+static_assert(kEpochWrap < (1u << (32 - kCountBits)), "epochs must fit the granule");
+static_assert(kRowSlots == kSuperRows + 1, "slot layout");
+static_assert(kSlotShift - 32 == kCountBits, "the high half of a slot carries its epoch where a granule does");
+static_assert(kScanBlockWords >= kSuperRows * kRowTiles + 2 * kRowSlots && kScanSlotsAt == kSuperRows * kRowTiles, "scan block layout");
 
-template <int W, bool kPair = false>
-__global__ __launch_bounds__((W + 1) * 64) void compress_kernel(const CompressArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 s_out[2][W][kOutWords];
-    __shared__ unsigned short s_pos[W][kPosEntries];
-    __shared__ u32 s_count[kDepth][W];    // words per worker of tile (gen % kDepth)
-    __shared__ u32 s_prefix[kDepth][W];   // ... and the words of the workers before it
-    __shared__ u32 s_arrived[kDepth];     // workers that have delivered their count for tile (gen % kDepth)
-    __shared__ u32 s_total[kDepth];       // words of tile (gen % kDepth) ...
-    __shared__ u32 s_total_flag[kDepth];  // ... valid when == gen + 1
-    __shared__ u64 s_base[kDepth];        // output offset of tile (gen % kDepth) ...
-    __shared__ u32 s_base_flag[kDepth];   // ... valid when == gen + 1
-    __shared__ u32 s_arrival;
+constexpr int kAuxSc1 = 16; // buffer load cache policy: sc1 = agent scope (served past the XCD-private caches)
+
+struct TileScan {
+    u32x4 a, b; // granules of my row (entries below me; the descriptor cuts the rest off) and of the previous row
+    u64 c;      // slot of my superrow: lane 0 = words in front of it, lane 1 + k = words of its row k
+};
+
+struct ScanGeom {
+    u32 row, idx, sup, row0; // tile = row * kRowTiles + idx; superrow of the row and its first row
+    u32 n_slots;             // slots to read: [0] and the rows row0 .. row - 2
+    bool has_prev;           // the previous row belongs to the same superrow (else slot[0] covers it)
+};
+
+__device__ __forceinline__ ScanGeom scan_geom(u32 tile) {
+    ScanGeom g;
+    g.row = tile / kRowTiles;
+    g.idx = tile % kRowTiles;
+    g.sup = g.row / kSuperRows;
+    g.row0 = g.sup * kSuperRows;
+    g.has_prev = g.row > g.row0;
+    g.n_slots = g.has_prev ? g.row - g.row0 : 1u;
+    return g;
+}
+
+__device__ __forceinline__ void scan_issue(const CompressArgs &a, const ScanGeom &g, u32 lane, bool need_a, bool need_b, bool need_c,
+                                           TileScan &p) {
+    u32 *const block = a.gen_desc + (u64)g.sup * kScanBlockWords; // my superrow's granules and slots
+    if (need_a) {
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(block + (g.row - g.row0) * kRowTiles, g.idx * 4u);
+        p.a = __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 16u, 0, kAuxSc1);
+    }
+    if (need_b) {
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(block + (g.row - 1u - g.row0) * kRowTiles, kRowTiles * 4u);
+        p.b = __builtin_amdgcn_raw_buffer_load_b128(rb, lane * 16u, 0, kAuxSc1);
+    }
+    if (need_c) {
+        const __amdgpu_buffer_rsrc_t rc = make_rsrc(block + kScanSlotsAt, g.n_slots * 8u);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rc, lane * 8u, 0, kAuxSc1);
+        p.c = ((u64)v.y << 32) | v.x;
+    }
+}
+
+// final words of one compacted segment (kernels.cu:244-249), from the wave's LDS buffer into 16 registers per lane:
+// word k * 64 + lane -> out[k].  Fill length = distance between consecutive run ends: a lane reads the position of ITS
+// run end, the previous one comes from the lane below by DPP (lane 0: from lane 63 of the batch before, -1 in front of
+// the first).  Batches of 256 words: 8 LDS reads in flight, then the arithmetic.  Words behind `count` are garbage that
+// is never stored.
+__device__ __forceinline__ void final_words_to_regs(const u32 *stage, const unsigned short *pos, u32 lane, u32 count, bool any_fill,
+                                                    u32 (&out)[16]) {
+    const u32 *const s0 = stage + lane;
+    const unsigned short *const q1 = pos + 1u + lane;
+    u32 prev_e = 0xFFFFu; // position "-1"
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (256u * t < count) {
+            u32 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = s0[256u * t + 64u * k];
+            if (any_fill) {
+                u32 e[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = q1[256u * t + 64u * k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // lane 0 <- lane 63 of the batch before (wave_ror:1), lanes 1.. <- the lane below (wave_shr:1)
+                    const u32 carry = (u32)__builtin_amdgcn_mov_dpp((int)prev_e, 0x13C /* wave_ror:1 */, 0xf, 0xf, true);
+                    const u32 p0 = (u32)__builtin_amdgcn_update_dpp((int)carry, (int)e[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                    const u32 len = (e[k] - p0) & 0xFFFFu;
+                    out[4 * t + k] = v[k] - 1u >= 0x7FFFFFFEu ? (((v[k] & 0x40000000u) | kFillZero) | len) : v[k];
+                    prev_e = e[k];
+                }
+            } else { // literals only: the compacted words are the final words
+#pragma unroll
+                for (int k = 0; k < 4; ++k) out[4 * t + k] = v[k];
+            }
+        }
+    }
+}
+
+// ... and from the registers to their place in the output (kernels.cu:256 + moveData, kernels.cu:273-280): dense
+// 256-byte stores through a descriptor that ends with the segment's words (and with the output's capacity: words past
+// it are dropped by the hardware; the last tile raises the capacity error)
+__device__ __forceinline__ void emit_regs(const CompressArgs &a, u64 base, u32 count, u32 lane, const u32 (&out)[16]) {
+    if (base >= a.out_capacity || count == 0u) return;
+    const u64 room = a.out_capacity - base;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + base, (room < count ? (u32)room : count) * 4u);
+    const u32 off = lane * 4u;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (256u * t < count) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(out[4 * t + k], rsrc, off + 256u * (4 * t + k), 0, 0);
+        }
+    }
+}
+
+template <bool kPair, bool kAligned>
+__global__ __launch_bounds__(kTileWaves * 64, 6) void compress_tile_kernel(const CompressArgs a) {
+    __shared__ __attribute__((aligned(16))) u32 s_out[kTileWaves][kOutWords];
+    __shared__ unsigned short s_pos[kTileWaves][kPosEntries];
+    __shared__ u32 s_count[kTileWaves];
+    __shared__ u32 s_prefix[kTileWaves];
+    __shared__ u64 s_base;
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
-    const bool worker = wave < (u32)W;
+    const u32 tile = blockIdx.x;
+    const u32 seg0 = (tile * kTileWaves + wave) * kWaveSegs; // this wave's segments: seg0, seg0 + 1
+#ifdef WAH_DIAG
+    u64 dg_t[6];
+    u32 dg_polls = 0;
+    dg_t[0] = __builtin_amdgcn_s_memrealtime();
+#define DG(i) dg_t[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define DG(i)
+#endif
 
-    if (threadIdx.x < kDepth) {
-        s_arrived[threadIdx.x] = 0;
-        s_total_flag[threadIdx.x] = 0;
-        s_base_flag[threadIdx.x] = 0;
-    }
-    if (threadIdx.x == 0) s_arrival = draw_arrival(a.ctrl);
-    __syncthreads();
-    const u32 arrival = uniform32(s_arrival);
-
-    if (a.census) {
-        // residency census: how many workgroups of this kernel are running together?  Everybody that is resident
-        // arrives within about a microsecond; whoever is not cannot start before a resident one exits.
-        // EVERY wave stays for the whole census (the barrier below): a wave that left early would give back its
-        // slot and registers, and more workgroups would fit than in the real run.
-        if (threadIdx.x == 0) {
-            const u64 t0 = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t0 < 3000) __builtin_amdgcn_s_sleep(8); // 30 us (100 MHz)
-            if (arrival == 0)
-                a.ctrl[kCtlCensus] = __hip_atomic_load(a.ctrl + kCtlStart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
+    // ---- launch epoch (same value for every workgroup of the launch: only the last tile's scan advances it) -------
+    const u32 stored_epoch = uniform32(a.ctrl[kCtlEpoch]);
+    const u32 magic = uniform32(a.ctrl[kCtlMagic]);
+    if (magic != 0u && magic != kWorkspaceMagic) { // neither a zeroed nor a used workspace
+        if (threadIdx.x == 0) atomicOr(a.ctrl + kCtlError, kErrWorkspace);
+        if (tile == a.n_tiles - 1 && threadIdx.x == 0) *a.out_words = 0;
         return;
     }
-
-    const u32 stride = gridDim.x;
-    const u32 row_stride = (stride + 3u) & ~3u;
-    WAH_STAMP_DECL
-
-    if (worker)
-        __builtin_amdgcn_s_setprio(1);
-    else
-        __builtin_amdgcn_s_setprio(2);
-    if (!worker) {
-        // ---------------- scan wave: resolve output offsets, tile after tile, as the counts come in ------------
-        GenScan scan = {0, 0, 0};
-        u32 gen = 0;
-        for (u32 tile = arrival; tile < a.n_tiles; tile += stride, ++gen) {
-            const u32 q = gen & (kDepth - 1u);
-            if (!lds_wait(&s_total_flag[q], gen + 1u, a.ctrl, lane)) break;
-            const u32 aggregate = uniform32(lds_ld(&s_total[q]));
-            WAH_STAMP(0);
-            const u64 excl = resolve_generation(a.gen_desc, gen, arrival, stride, row_stride, aggregate, scan, lane, a.ctrl);
-            WAH_STAMP(1);
-#ifdef WAH_DIAG
-            if (lane == 0 && a.seg_offsets) {
-                a.seg_offsets[(u64)tile * 4 + 2] = __builtin_amdgcn_s_memrealtime();
-                a.seg_offsets[(u64)tile * 4 + 3] = ((u64)blockIdx.x << 32) | gen;
-            }
-#endif
-            if (lane == 0) {
-                __hip_atomic_store((lds_u64_ptr)&s_base[q], excl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                lds_publish(&s_base_flag[q], gen + 1u);
-                if (tile == a.n_tiles - 1) {
-                    *a.out_words = excl + aggregate;
-#ifndef WAH_DIAG
-                    if (a.seg_offsets) a.seg_offsets[a.n_segments] = excl + aggregate;
-#endif
+    const bool wrap = stored_epoch >= kEpochWrap;
+    const u32 epoch = (stored_epoch == 0u || wrap) ? 1u : stored_epoch;
+    if (wrap) {
+        // the epoch space is used up: stale granules could be taken for this launch's.  Tile 0 clears the scan
+        // area, everybody else waits for that (tile 0 has the smallest blockIdx: it is running).
+        const u32 wraps = uniform32(a.ctrl[kCtlWraps]);
+        if (tile == 0) {
+            for (u64 k = threadIdx.x; k < a.scan_words; k += blockDim.x)
+                __hip_atomic_store(a.gen_desc + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(a.ctrl + kCtlClearDone, wraps + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (threadIdx.x == 0) {
+                u32 spins = 0;
+                while (__hip_atomic_load(a.ctrl + kCtlClearDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wraps + 1u) {
+                    if (++spins > kMaxSpins) {
+                        atomicOr(a.ctrl + kCtlError, kErrTimeout);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
                 }
-                if (excl + aggregate > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
             }
-#ifdef WAH_DIAG
-            dg_acc[7] += 1;
-#endif
+            __syncthreads();
         }
-#ifdef WAH_DIAG
-        if (lane == 0)
-            for (int i = 0; i < 2; ++i)
-                atomicAdd(reinterpret_cast<unsigned long long *>(a.ctrl + 192) + 8 + i, (unsigned long long)dg_acc[i]);
-#endif
-        return;
+    }
+    if (tile == 0 && threadIdx.x == 0 && !a.keep_error) {
+        // a new launch: forget the previous one's status.  Completed before this tile publishes anything, and every
+        // error of this launch is raised by a tile that has seen something published.
+        __hip_atomic_store(a.ctrl + kCtlError, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
-    // ---------------- worker waves -------------------------------------------------------------------------
-    // Each worker owns two 4 KiB LDS buffers.  One is the STAGE: the segment is staged, classified and compacted
-    // there.  The other is a RING of finished output words that wait for their global offset: up to kMaxPending
-    // tiles (as many as fit 1024 words), oldest first.  So the offset of a tile is not needed one iteration after
-    // it was published (the resolve latency across the chip is about one iteration of work, measured) but only
-    // when the ring runs out of room -- two or three iterations later for compressible data.  A segment that does
-    // not fit beside what is pending (incompressible data) waits for the ring to drain and then the two buffers
-    // simply swap roles, without copying.
-    // regroup constants: group g = 64*step + lane starts at stream bit 31*g; 64 groups = 1984 bits = 62 words
-    // exactly, so the in-word shift is fixed per lane and the word index advances by 62 per step
-    const u32 r = (31u * lane) & 31u;
+    // ---- this wave's segments, one after the other through the wave's LDS buffer; the final words of each are parked
+    //      in 16 registers per lane, so nothing of a tile that waits for its offset occupies LDS bandwidth or needs a
+    //      second LDS pass, and twice as many segments are in flight per CU as there are LDS buffers -------------------
+    u32 *const stage = s_out[wave];
     unsigned short *const pos = s_pos[wave];
-
+    const u32 r = (31u * lane) & 31u;
+    const u32 *const sp = stage + ((31u * lane) >> 5);
+    u32 out[kWaveSegs][16];
+    u32 cnt[kWaveSegs];
     Prefetch pre, pre2; // pre2: pair mode only (wah_bitop_device), the second bitmap's words
-    pre.v[0] = pre.v[1] = pre.v[2] = pre.v[3] = u32x4{0, 0, 0, 0};
-    pre2 = pre;
-    // wave-uniform: `pre` holds the current tile's segment (always, unless the input is only 4-byte aligned)
-    bool pre_valid = false;
-    {
-        const u32 seg = arrival * W + wave;
-        if (arrival < a.n_tiles && seg < a.n_segments && a.fast_segments) {
-            prefetch_segment(a, seg, lane, pre);
-            if (kPair) prefetch_segment2(a, seg, lane, pre2);
-            pre_valid = true;
-        }
+    if (seg0 < a.n_segments) {
+        prefetch_segment<kAligned>(a.in, a, seg0, lane, pre);
+        if (kPair) prefetch_segment<kAligned>(a.in2, a, seg0, lane, pre2);
     }
-
-    u32 *stage = s_out[0][wave];
-    u32 *ring = s_out[1][wave];
-    u32 pend = 0;                       // tiles in the ring: generations gen - pend .. gen - 1
-    u32 ring_head = 0;                  // ring index of the oldest pending word
-    u32 used = 0;                       // pending words
-    u32 pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0; // their word counts, oldest first
-    bool ok = true;
-
-    // stream out the oldest pending tile (kernels.cu:256 + moveData, kernels.cu:273-280); `block`: wait for its offset
-    auto emit_oldest = [&](u32 gen_now, bool block, u32 lane_v) -> bool {
-        const u32 pgen = gen_now - pend;
-        const u32 q = pgen & (kDepth - 1u);
-        if (lds_ld(&s_base_flag[q]) != pgen + 1u) {
-            if (!block) return false;
-            if (!lds_wait(&s_base_flag[q], pgen + 1u, a.ctrl, lane)) {
-                ok = false;
-                return false;
-            }
-        }
-        WAH_STAMP(3);
-        const u32 pseg = (arrival + pgen * stride) * W + wave;
-        const u32 cnt = pc0;
-        if (pseg < a.n_segments) {
-            const u64 base = uniform64(lds_ld64(&s_base[q])) + uniform32(lds_ld(&s_prefix[q][wave]));
-#ifndef WAH_DIAG
-            if (lane == 0 && a.seg_offsets) a.seg_offsets[pseg] = base;
-#endif
-            if (base < a.out_capacity && cnt != 0u) {
-                // descriptor over this segment's slice of the output (clipped to the capacity: words past it
-                // are dropped by the hardware, and the scan wave has already raised the capacity error)
-                const u64 room = a.out_capacity - base;
-                const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + base, (room < cnt ? (u32)room : cnt) * 4u);
-                const u32 off = lane_v * 4u;
-                if (ring_head + ((cnt + 255u) & ~255u) <= kStageWords) {
-                    // no wrap inside the trips (reads behind the last word stay inside the buffer): plain addressing
-                    const u32 *const r0 = ring + ring_head + lane_v;
-                    for (u32 t = 0; t < cnt; t += 256u) { // four LDS reads in flight, then four dense stores
-                        u32 v[4];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = r0[t + 64u * k];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(v[k], rsrc, off + 256u * k, t * 4u, 0);
-                    }
-                } else {
-                    for (u32 t = 0; t < cnt; t += 256u) {
-                        u32 v[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = ring[(ring_head + t + lane_v + 64u * k) & (kStageWords - 1u)];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(v[k], rsrc, off + 256u * k, t * 4u, 0);
-                    }
-                }
-            }
-        }
-        ring_head = (ring_head + cnt) & (kStageWords - 1u);
-        used -= cnt;
-        pc0 = pc1;
-        pc1 = pc2;
-        pc2 = pc3;
-        pc3 = 0;
-        --pend;
-        // later iterations overwrite these words: order the reads before those writes
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        WAH_STAMP(4);
-        return true;
-    };
-
-    // the last segment compressed to a handful of words: the next one probably consists of long fills too
-    constexpr u32 kLongFillsBelow = 256;
-    bool long_fills = false, whole_run = false;
-    u32 gen = 0;
-    for (u32 tile = arrival; tile < a.n_tiles && ok; tile += stride, ++gen) {
-        const u32 seg = tile * W + wave;
-        u32 count = 0;
-        // Opaque copy of the lane id, renewed every iteration: per-step constants derived from it (group
-        // positions, LDS addresses) are then recomputed next to their use instead of being hoisted out of the
-        // persistent loop, where 16 + 16 of them would be kept live and spilled.
-        u32 lane_v = lane;
-        asm volatile("" : "+v"(lane_v));
-#ifdef WAH_DIAG
-        if (threadIdx.x == 0 && a.seg_offsets) a.seg_offsets[(u64)tile * 4 + 0] = __builtin_amdgcn_s_memrealtime();
-#endif
-        const bool has_seg = seg < a.n_segments;
-        if (kPair && pre_valid) combine_pair(pre, pre2, a.op); // from here on `pre` is the combined bitmap
-        // Inside a very long run (the wave's last segment was one or two words) the whole segment is probably one
-        // fill: decide that from the prefetched registers -- all 992 words zero, or all ones -- and skip staging and
-        // classification.  (Lanes 56..63 of the fourth load lie behind the segment and read as zero.)
-        u32 uniform_kind = 0; // 1: all zero, 2: all ones
-        if (has_seg && pre_valid && whole_run && seg + 1u < a.n_segments) {
-            const u32x4 o = pre.v[0] | pre.v[1] | pre.v[2] | pre.v[3];
-            const u32x4 tail_fix = lane >= 56u ? u32x4{~0u, ~0u, ~0u, ~0u} : u32x4{0, 0, 0, 0};
-            const u32x4 n = pre.v[0] & pre.v[1] & pre.v[2] & (pre.v[3] | tail_fix);
-            if (__ballot((o.x | o.y | o.z | o.w) != 0u) == 0)
-                uniform_kind = 1;
-            else if (__ballot((n.x & n.y & n.z & n.w) != ~0u) == 0)
-                uniform_kind = 2;
-        }
-        if (has_seg && !uniform_kind) {
-            if (pre_valid)
-                stage_prefetched(pre, stage, lane);
-            else
-                stage_slow(a, seg, stage, lane);
-        }
-        // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        WAH_STAMP(0);
-
-        // software prefetch of the next tile's segment: in flight during everything below
-        {
-            const u32 next_tile = tile + stride;
-            const u32 nseg = next_tile * W + wave;
-            pre_valid = next_tile < a.n_tiles && nseg < a.n_segments && a.fast_segments;
-            if (pre_valid) {
-                prefetch_segment(a, nseg, lane, pre);
-                if (kPair) prefetch_segment2(a, nseg, lane, pre2);
-            }
-        }
-
-        bool any_fill = false;
-        if (uniform_kind) {
-            // one run end, at the last group: what classify_compact would have left in the stage buffer
-            if (lane == 0) {
-                stage[0] = uniform_kind == 1 ? 0u : kOnes31;
-                pos[0] = 0xFFFFu;
-                pos[1] = (unsigned short)(kSegGroups - 1u);
-            }
-            count = 1;
-            any_fill = true;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        } else if (has_seg) {
-            const u32 nvalid = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
+    for (u32 j = 0; j < kWaveSegs; ++j) {
+        const u32 seg = seg0 + j;
+        cnt[j] = 0;
+        if (seg < a.n_segments) {
+            if (kPair) combine_pair(pre, pre2, a.op);
+            stage_prefetched(pre, stage, lane);
             if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
-            const u32 *sp = stage + ((31u * lane_v) >> 5);
-            count = nvalid == kSegGroups ? classify_compact<true>(sp, stage, pos, r, lane_v, nvalid, long_fills, any_fill)
-                                         : classify_compact<false>(sp, stage, pos, r, lane_v, nvalid, long_fills, any_fill);
-            long_fills = count < kLongFillsBelow;
-            whole_run = count <= 2u;
+            // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (j == 0) DG(1);
+            // the next segment's loads are in flight while this one is classified
+            if (j + 1 < kWaveSegs && seg + 1 < a.n_segments) {
+                prefetch_segment<kAligned>(a.in, a, seg + 1, lane, pre);
+                if (kPair) prefetch_segment<kAligned>(a.in2, a, seg + 1, lane, pre2);
+            }
+            const u32 nvalid = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
+            bool any_fill = false;
+            cnt[j] = classify_compact(sp, stage, pos, r, lane, nvalid, any_fill);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            final_words_to_regs(stage, pos, lane, cnt[j], any_fill, out[j]);
+            // the buffer is staged over next: order these reads before those writes
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        WAH_STAMP(1);
+    }
+    u32 count = 0;
+#pragma unroll
+    for (u32 j = 0; j < kWaveSegs; ++j) count += cnt[j];
+    if (lane == 0) s_count[wave] = count;
+    DG(2);
+    __syncthreads();
+    DG(3);
 
-        // deliver the count (nothing else of this tile is needed to resolve offsets); the last worker to arrive
-        // publishes the tile's total to the other workgroups (one 4-byte granule, see resolve_generation) and to
-        // the scan wave
-        {
-            const u32 q = gen & (kDepth - 1u);
-            u32 last = 0;
-            if (lane == 0) {
-                lds_st(&s_count[q][wave], count);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                last = __hip_atomic_fetch_add((lds_u32_ptr)&s_arrived[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (u32)W - 1u;
-            }
-            if (uniform32(last)) {
-                // lane w: words of worker w -> DPP scan -> every worker's offset inside the tile, and the total
-                const u32 mine = lane < (u32)W ? lds_ld(&s_count[q][lane]) : 0u;
-                const u32 incl = wave_scan_incl32(mine);
-                if (lane < (u32)W) lds_st(&s_prefix[q][lane], incl - mine);
-                const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-                if (lane == 0) {
-#ifdef WAH_DIAG
-                    if (a.seg_offsets) a.seg_offsets[(u64)tile * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
-                    publish_generation(a.gen_desc, gen, arrival, row_stride, total);
-                    lds_st(&s_arrived[q], 0u);
-                    lds_st(&s_total[q], total);
-                    lds_publish(&s_total_flag[q], gen + 1u);
+    if (wave == 0) {
+        // ---- the tile's count, then its offset -------------------------------------------------------------------
+        const u32 mine = lane < kTileWaves ? s_count[lane] : 0u;
+        const u32 incl = wave_scan_incl32(mine);
+        if (lane < kTileWaves) s_prefix[lane] = incl - mine;
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        const ScanGeom g = scan_geom(tile);
+        u32 *const block = a.gen_desc + (u64)g.sup * kScanBlockWords;
+        if (lane == 0)
+            __hip_atomic_store(block + (g.row - g.row0) * kRowTiles + g.idx, (epoch << kCountBits) | total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+
+        // One round trip of three loads per lane, issued now that the count is out: by the time they are served, the
+        // tiles dispatched before this one have normally published theirs.  If something is still missing, the wave
+        // does NOT sweep again and again (hundreds of waiting tiles re-reading 2.5 KB each every microsecond is traffic
+        // of the order of the bitmap's): it spins on ONE word, the missing entry with the highest tile number -- the one
+        // that will be published last -- and sweeps again when that one is there.
+        bool need_a = true, need_b = g.has_prev, need_c = true;
+        TileScan poll = {};
+        scan_issue(a, g, lane, need_a, need_b, need_c, poll);
+        u32 sum_a = 0, sum_b = 0;
+        u64 sum_c = 0;
+        u32 spins = 0;
+        for (;;) {
+            u32 bad_a = 0, bad_b = 0; // per lane: which of my four entries are missing
+            bool bad_c = false;
+            u64 ba = 0, bb = 0, bc = 0;
+            if (need_a) {
+                const u32 k0 = 4u * lane;
+                bad_a = ((k0 < g.idx && (poll.a.x >> kCountBits) != epoch) ? 1u : 0u) | ((k0 + 1u < g.idx && (poll.a.y >> kCountBits) != epoch) ? 2u : 0u) |
+                        ((k0 + 2u < g.idx && (poll.a.z >> kCountBits) != epoch) ? 4u : 0u) | ((k0 + 3u < g.idx && (poll.a.w >> kCountBits) != epoch) ? 8u : 0u);
+                ba = __ballot(bad_a != 0u);
+                if (ba == 0) {
+                    // entries at and above my index lie behind the descriptor and read as zero
+                    sum_a = uniform32(wave_sum32((poll.a.x & kCountMask) + (poll.a.y & kCountMask) + (poll.a.z & kCountMask) + (poll.a.w & kCountMask)));
+                    need_a = false;
+                    // my row is complete with me: its total is all that later superrow-mates need of it
+                    if (g.idx == kRowTiles - 1u && lane == 0)
+                        __hip_atomic_store(reinterpret_cast<u64 *>(block + kScanSlotsAt) + 1u + (g.row - g.row0),
+                                           ((u64)epoch << kSlotShift) | ((u64)sum_a + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-        }
-        WAH_STAMP(2);
-
-        // room in the ring for this tile's words (every wait here is for an offset published >= 1 iteration ago)
-        while (ok && pend != 0u && (pend == kMaxPending || used + count > kStageWords)) (void)emit_oldest(gen, true, lane_v);
-        if (!ok) break;
-        const bool in_place = pend == 0u; // ring empty: the stage buffer BECOMES the ring, nothing is copied
-        if (in_place) {
-            u32 *const t = stage;
-            stage = ring;
-            ring = t;
-            ring_head = 0;
-        }
-        if (any_fill || !in_place) {
-            // final words (kernels.cu:244-249): fill length = distance between consecutive run ends; written to the
-            // ring behind what is pending (or in place).  Four batches (256 words) per trip: 12 LDS reads in flight,
-            // then the arithmetic, then 4 writes; every lane rewrites its word (unchanged if a literal).
-            const u32 *const src = in_place ? ring : stage;
-            const u32 tail = (ring_head + used) & (kStageWords - 1u);
-            const u32 padded = (count + 63u) & ~63u; // whole 64-word batches
-            // one word: fill -> type | length, literal -> itself
-            auto final_word = [](u32 v, u32 p1, u32 p0) {
-                const u32 len = (p1 - p0) & 0xFFFFu;
-                return v - 1u >= 0x7FFFFFFEu ? ((v ? kFillOne : kFillZero) | len) : v;
-            };
-            if (tail + padded <= kStageWords && used + padded <= kStageWords) {
-                // usual case: the batches neither wrap around the ring nor reach the oldest pending words, so whole
-                // batches are written (the up to 63 words behind the last real one land on free ring space): no
-                // predicates, no wrap arithmetic, every address is one register + an immediate
-                const u32 *const s0 = src + lane_v;
-                const unsigned short *const q0 = pos + lane_v;
-                u32 *const d0 = ring + tail + lane_v;
-                for (u32 t = 0; t < padded; t += 256u) {
-                    const u32 left = padded - t; // 64, 128, 192 or >= 256
-                    u32 v[4], p1[4], p0[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (64u * k < left) {
-                            v[k] = s0[t + 64u * k];
-                            p1[k] = q0[t + 64u * k + 1u];
-                            p0[k] = q0[t + 64u * k];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (64u * k < left) d0[t + 64u * k] = final_word(v[k], p1[k], p0[k]);
+            if (need_b) {
+                bad_b = ((poll.b.x >> kCountBits) != epoch ? 1u : 0u) | ((poll.b.y >> kCountBits) != epoch ? 2u : 0u) |
+                        ((poll.b.z >> kCountBits) != epoch ? 4u : 0u) | ((poll.b.w >> kCountBits) != epoch ? 8u : 0u);
+                bb = __ballot(bad_b != 0u);
+                if (bb == 0) {
+                    sum_b = uniform32(wave_sum32((poll.b.x & kCountMask) + (poll.b.y & kCountMask) + (poll.b.z & kCountMask) + (poll.b.w & kCountMask)));
+                    need_b = false;
                 }
+            }
+            if (need_c) {
+                // slot 0 of superrow 0 is never written: nothing lies in front of the first tile
+                const bool wanted = lane < g.n_slots && !(g.sup == 0u && lane == 0u);
+                bad_c = wanted && (u32)(poll.c >> kSlotShift) != epoch;
+                bc = __ballot(bad_c);
+                if (bc == 0) {
+                    sum_c = uniform64(wave_sum(wanted ? poll.c & kSlotMask : 0ull));
+                    need_c = false;
+                }
+            }
+            if (!(need_a || need_b || need_c)) break;
+            // the word to wait for: {epoch, ...} in its top bits, whichever array it belongs to
+            const u32 *target;
+            if (need_a) {
+                const u32 hl = 63u - (u32)__builtin_clzll(ba);
+                const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_a, (int)hl);
+                target = block + (g.row - g.row0) * kRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
+            } else if (need_b) {
+                const u32 hl = 63u - (u32)__builtin_clzll(bb);
+                const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_b, (int)hl);
+                target = block + (g.row - 1u - g.row0) * kRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
             } else {
-                for (u32 t = 0; t < count; t += 256u) {
-                    u32 v[4], p1[4], p0[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const u32 j = t + lane_v + 64u * k;
-                        v[k] = src[j];
-                        p1[k] = pos[j + 1u];
-                        p0[k] = pos[j];
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const u32 j = t + lane_v + 64u * k;
-                        if (j < count) ring[(tail + j) & (kStageWords - 1u)] = final_word(v[k], p1[k], p0[k]);
-                    }
+                const u32 hl = 63u - (u32)__builtin_clzll(bc);
+                target = block + kScanSlotsAt + 2u * hl + 1u; // high half of the slot
+            }
+            bool timed_out = false;
+            for (;;) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((__hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> kCountBits) == epoch) break;
+                if (++spins > kMaxSpins) {
+                    timed_out = true;
+                    break;
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (timed_out) {
+                if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
+                break;
+            }
+            scan_issue(a, g, lane, need_a, need_b, need_c, poll);
+#ifdef WAH_DIAG
+            ++dg_polls;
+#endif
         }
-        // push
-        if (pend == 0u) pc0 = count;
-        else if (pend == 1u) pc1 = count;
-        else if (pend == 2u) pc2 = count;
-        else pc3 = count;
-        ++pend;
-        used += count;
-        WAH_STAMP(5);
+        DG(4);
+        const u64 base = sum_c + sum_b + sum_a;
+        const u64 end = base + total;
+        if (lane == 0) {
+            s_base = base;
+            if (g.idx == kRowTiles - 1u && g.row - g.row0 == kSuperRows - 1u) // last tile of a superrow
+                __hip_atomic_store(reinterpret_cast<u64 *>(a.gen_desc + (u64)(g.sup + 1u) * kScanBlockWords + kScanSlotsAt),
+                                   ((u64)epoch << kSlotShift) | end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tile == a.n_tiles - 1) {
+                *a.out_words = end;
+                if (a.seg_offsets) a.seg_offsets[a.n_segments] = end;
+                if (end > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+                // every other tile has published its granule, so it has read the epoch: advance it for the next launch
+                if (wrap) __hip_atomic_store(a.ctrl + kCtlWraps, uniform32(a.ctrl[kCtlWraps]) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.ctrl + kCtlMagic, kWorkspaceMagic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.ctrl + kCtlEpoch, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    __syncthreads();
+#ifdef WAH_DIAG
+    if (wave == 0 && lane == 0 && (tile & 63u) == 0u) { // a sample: the atomics must not become the bottleneck
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(a.ctrl + 192);
+        atomicAdd(d + 0, (unsigned long long)(dg_t[1] - dg_t[0])); // loads -> staged
+        atomicAdd(d + 1, (unsigned long long)(dg_t[2] - dg_t[1])); // classify
+        atomicAdd(d + 2, (unsigned long long)(dg_t[3] - dg_t[2])); // barrier 1 (slowest wave of the tile)
+        atomicAdd(d + 3, (unsigned long long)(dg_t[4] - dg_t[3])); // scan
+        atomicAdd(d + 4, (unsigned long long)dg_polls);
+        atomicAdd(d + 5, 1ull);
+        atomicAdd(d + 6, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dg_t[0]));
+    }
+#endif
 
-        // (Pending tiles are emitted only when the ring needs the room, above: trying here as well -- "stream out
-        // whatever has its offset already" -- costs an LDS poll per iteration that mostly fails and moves the emission in
-        // front of the next tile's loads; without it the sparse GiB takes 0.349 instead of 0.373 ms, clustered 0.255
-        // instead of 0.270, dense the same.)
-#ifdef WAH_DIAG
-        dg_acc[7] += 1;
-#endif
+    // ---- the parked words to their place ---------------------------------------------------------------------------
+    u64 base = uniform64(s_base) + uniform32(s_prefix[wave]);
+#pragma unroll
+    for (u32 j = 0; j < kWaveSegs; ++j) {
+        const u32 seg = seg0 + j;
+        if (seg < a.n_segments) {
+            if (lane == 0 && a.seg_offsets) a.seg_offsets[seg] = base;
+            emit_regs(a, base, cnt[j], lane, out[j]);
+            base += cnt[j];
+        }
     }
-    while (ok && pend != 0u) { // drain
-        u32 lane_v = lane;
-        asm volatile("" : "+v"(lane_v));
-        (void)emit_oldest(gen, true, lane_v);
-    }
-    WAH_STAMP_FLUSH(a.ctrl);
-#ifdef WAH_DIAG
-    if (lane == 0 && a.seg_offsets && blockIdx.x < 64) { // per-wave phase totals of the first 64 workgroups
-        for (int i = 0; i < 8; ++i)
-            a.seg_offsets[(u64)a.n_tiles * 4 + (u64)gridDim.x * 10 + ((u64)blockIdx.x * 16 + wave) * 8 + i] = dg_acc[i];
-    }
-    if (threadIdx.x == 0 && a.seg_offsets) {
-        u32 xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        for (int i = 0; i < 8; ++i) a.seg_offsets[(u64)a.n_tiles * 4 + (u64)blockIdx.x * 10 + i] = dg_acc[i];
-        a.seg_offsets[(u64)a.n_tiles * 4 + (u64)blockIdx.x * 10 + 8] = xcc;
-        a.seg_offsets[(u64)a.n_tiles * 4 + (u64)blockIdx.x * 10 + 9] = arrival;
-    }
-#endif
 }
 
 } // namespace
 
-// Grid of the persistent compress kernel = how many of its workgroups are resident together, measured once per
-// device by a census launch of the same kernel (the occupancy API is advisory: MI355X_MICROARCH residency notes).
-
-template <int W>
-int compress_grid_for(u32 *d_ctrl, hipStream_t s) {
-    static int cached[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (cached[dev] > 0) return cached[dev];
-    const int upper = persistent_grid(reinterpret_cast<const void *>(&compress_kernel<W>), (W + 1) * 64, ~0ull);
-    CompressArgs a = {};
-    a.ctrl = d_ctrl;
-    a.census = 1;
-    int resident = 0;
-    if (launch_clear(d_ctrl, kCtlWords * sizeof(u32), s) == hipSuccess) {
-        hipLaunchKernelGGL(compress_kernel<W>, dim3(upper), dim3((W + 1) * 64), 0, s, a);
-        u32 seen = 0;
-        if (hipGetLastError() == hipSuccess &&
-            hipMemcpyAsync(&seen, d_ctrl + kCtlCensus, sizeof seen, hipMemcpyDeviceToHost, s) == hipSuccess &&
-            hipStreamSynchronize(s) == hipSuccess)
-            resident = (int)seen;
-    }
-    if (resident < 1) return -1;
-    if (resident > upper) resident = upper;
-    resident = whole_per_cu(resident);
-    cached[dev] = resident;
-    return resident;
-}
-
-int compress_grid(int workers, u32 *d_ctrl, hipStream_t s) {
-    return workers == 15 ? compress_grid_for<15>(d_ctrl, s) : compress_grid_for<7>(d_ctrl, s);
-}
-
-hipError_t launch_compress(int workers, const CompressArgs &a, int grid, hipStream_t s) {
-    if (workers == 15)
-        hipLaunchKernelGGL(compress_kernel<15>, dim3(grid), dim3(16 * 64), 0, s, a);
-    else
-        hipLaunchKernelGGL(compress_kernel<7>, dim3(grid), dim3(8 * 64), 0, s, a);
+hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {
+    if (a.in2)
+        hipLaunchKernelGGL((compress_tile_kernel<true, true>), dim3(a.n_tiles), dim3(kTileWaves * 64), 0, s, a);
+    else if (a.fast_segments)
+        hipLaunchKernelGGL((compress_tile_kernel<false, true>), dim3(a.n_tiles), dim3(kTileWaves * 64), 0, s, a);
+    else // input only 4-byte aligned: dword loads
+        hipLaunchKernelGGL((compress_tile_kernel<false, false>), dim3(a.n_tiles), dim3(kTileWaves * 64), 0, s, a);
     return hipGetLastError();
 }
 
@@ -667,12 +585,6 @@ __global__ void bitop_check_kernel(const u64 *info_a, const u64 *info_b, const u
 hipError_t launch_bitop_check(const u64 *info_a, const u64 *info_b, const u32 *ctrl_a, const u32 *ctrl_b, u64 groups, u32 *ctrl,
                               hipStream_t s) {
     hipLaunchKernelGGL(bitop_check_kernel, dim3(1), dim3(64), 0, s, info_a, info_b, ctrl_a, ctrl_b, groups, ctrl);
-    return hipGetLastError();
-}
-
-// pair mode (wah_bitop_device): same kernel, two inputs combined while they are staged; needs the fast path
-hipError_t launch_compress_pair(const CompressArgs &a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((compress_kernel<15, true>), dim3(grid), dim3(16 * 64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -192,6 +192,7 @@ __device__ __forceinline__ u64 resolve_generation(const u32 *gdesc, u32 gen, u32
 }
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 
 using lds_u32_ptr = __attribute__((address_space(3))) u32 *;
 using lds_u64_ptr = __attribute__((address_space(3))) u64 *;

@@ -19,20 +19,32 @@ constexpr uint32_t kSegWords = 992;
 constexpr uint32_t kSegGroups = 1024;
 constexpr uint32_t kSteps = 16; // 64 groups (one wavefront) per step
 
-// ---- inter-workgroup control block (uint32 words, zeroed before each launch)
-constexpr uint32_t kCtlStart = 0;        // arrival ticket: order in which workgroups start running
+// ---- inter-workgroup control block (uint32 words)
+// decode / aux kernels: zeroed before each launch.  compress: zeroed ONCE (wah_workspace_init_device), then kept up by
+// the kernel itself (launch epochs, see compress_tile_kernel).
+constexpr uint32_t kCtlStart = 0;        // arrival ticket: order in which workgroups start running (persistent kernels)
+constexpr uint32_t kCtlEpoch = 8;        // compress: epoch of the NEXT launch (0 = fresh workspace)
+constexpr uint32_t kCtlMagic = 9;        // compress: kWorkspaceMagic once a launch has completed (0 = fresh workspace)
+constexpr uint32_t kCtlWraps = 10;       // compress: how often the epoch space has been used up
+constexpr uint32_t kCtlClearDone = 11;   // compress: == kCtlWraps + 1 once tile 0 of a wrapping launch has cleared the scan area
 constexpr uint32_t kCtlError = 160;      // sticky error bits
 constexpr uint32_t kCtlCensus = 161;     // census mode: workgroups resident together
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
 constexpr uint32_t kErrTimeout = 1u;     // a bounded wait expired
 constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity
 constexpr uint32_t kErrStream = 4u;      // malformed compressed stream
+constexpr uint32_t kErrWorkspace = 8u;   // compress workspace neither zeroed nor left by an earlier launch
+constexpr uint32_t kWorkspaceMagic = 0x57414832u; // "WAH2"
+constexpr uint32_t kEpochWrap = (1u << 17) - 1u;  // stored epoch >= this: the next launch clears the scan area first
 
-// ---- compress geometry: one wavefront owns one segment --------------------
-// worker wavefronts = segments per tile: 7 (+1 scan wave = 512 threads, 2 workgroups per CU) or
-// 15 (+1 = 1024 threads, 1 workgroup per CU); WAH_WORKERS selects at run time for experiments
-constexpr int kCompressWavesDefault = 15;
-int compress_workers();
+// ---- compress geometry: one wavefront owns one segment, a workgroup (tile) kCompressTileWaves of them ------------
+constexpr int kCompressTileWaves = 8;
+constexpr int kCompressWaveSegs = 2; // segments a wavefront compresses one after the other
+// scan area of the compress kernel (see compress_tile_kernel): one block per superrow of 64 rows x 256 tiles
+constexpr uint32_t kRowSlots = 65;                 // u64 slots of a superrow: words in front of it, words of each of its rows
+constexpr uint32_t kScanSlotsAt = 64 * 256;        // 32-bit words: the slots follow the superrow's granules
+constexpr uint32_t kScanBlockWords = 64 * 256 + 256; // granules + slots, padded to 1 KiB
+constexpr uint64_t kScanBlockTiles = 64 * 256;
 
 // ---- decode geometry -------------------------------------------------------
 constexpr int kScanTileWords = 4096; // compressed words per tile (both decode passes)
@@ -45,7 +57,7 @@ struct CompressArgs {
     uint32_t op;           // ... with WAH_OP_AND / OR / XOR / ANDNOT
     uint64_t n_words;
     uint32_t n_segments;          // ceil(G / 1024)
-    uint32_t n_tiles;             // ceil(n_segments / kCompressWaves)
+    uint32_t n_tiles;             // ceil(n_segments / (kCompressTileWaves * kCompressWaveSegs))
     uint32_t fast_segments;       // 1: input 16-byte aligned -> prefetched buffer loads; 0: scalar staging
     uint32_t last_segment_groups; // groups of the last segment (1..1024)
     uint32_t full_segments;       // n_words / 992: segments that lie wholly inside the bitmap
@@ -55,8 +67,10 @@ struct CompressArgs {
     uint64_t *out_words;   // device scalar: C
     uint64_t *seg_offsets; // optional, n_segments + 1 entries
     uint32_t *ctrl;        // kCtlWords
-    uint32_t *gen_desc;    // generation rows: one 4-byte granule per tile (see resolve_generation)
-    int census;            // 1: residency census only (see compress_grid)
+    uint32_t *gen_desc;    // scan area: blocks of kScanBlockWords (see compress_tile_kernel)
+    uint64_t scan_words;   // 32-bit words of the whole scan area
+    int keep_error;        // 1: the control block was cleared by the caller and may already hold an upstream error
+    uint32_t tune;         // experiments only (WAH_TUNE)
 };
 
 struct ScanArgs {
@@ -126,11 +140,9 @@ struct PairCheck {
 };
 
 // launchers (wah_compress.hip, wah_decode.hip, wah_aux.hip)
-hipError_t launch_compress(int workers, const CompressArgs &a, int grid, hipStream_t s);
-hipError_t launch_compress_pair(const CompressArgs &a, int grid, hipStream_t s);
+hipError_t launch_compress(const CompressArgs &a, hipStream_t s); // pair mode when a.in2 != nullptr
 hipError_t launch_bitop_check(const uint64_t *info_a, const uint64_t *info_b, const uint32_t *ctrl_a, const uint32_t *ctrl_b, uint64_t groups,
                               uint32_t *ctrl, hipStream_t s);
-int compress_grid(int workers, uint32_t *d_ctrl, hipStream_t s);
 hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s);
 int decode_sums_grid(uint32_t *d_ctrl, hipStream_t s);
 hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t n_tiles, hipStream_t s);

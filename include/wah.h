@@ -32,7 +32,7 @@ extern "C" {
 /* status codes of the device-pointer API (0 = success) */
 #define WAH_OK 0
 #define WAH_ERR_ARG (-1)      /* null / misaligned pointer, size out of range        */
-#define WAH_ERR_WORKSPACE (-2) /* workspace too small                                 */
+#define WAH_ERR_WORKSPACE (-2) /* workspace too small, or never initialised           */
 #define WAH_ERR_HIP (-3)      /* a HIP runtime call failed (see wah_last_error())    */
 #define WAH_ERR_CAPACITY (-4) /* output buffer too small (reported by wah_*_status)  */
 #define WAH_ERR_TIMEOUT (-5)  /* an in-kernel bounded wait expired                   */
@@ -94,10 +94,19 @@ size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_wo
  * `stream` is a hipStream_t passed as void* (NULL = the default stream).
  * ------------------------------------------------------------------------- */
 
+/* The compress workspace is initialised ONCE (all zero bytes: this call, or any memset) and then keeps itself up:
+ * every launch stamps what it leaves there with a launch epoch, so nothing is cleared between launches, and one
+ * workspace may serve bitmaps of different sizes (up to the one it was sized for) in turn -- but only one launch at a
+ * time.  A workspace that is neither zeroed nor left by an earlier launch is reported as WAH_ERR_WORKSPACE by
+ * wah_compress_status().  Asynchronous on `stream`. */
+int wah_workspace_init_device(void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* d_in: n_words words, 16-byte aligned.  d_out: room for out_capacity_words
  * (wah_max_compressed_words(n) always suffices).  d_out_words: one device
- * uint64 that receives C.  Result status is left in the workspace; read it
- * with wah_compress_status() after the stream has been synchronised. */
+ * uint64 that receives C.  d_workspace: wah_compress_workspace_bytes(n_words) bytes or more, initialised as above.
+ * Result status is left in the workspace; read it with wah_compress_status() after the stream has been synchronised.
+ * One kernel launch, nothing else: no clearing pass, no residency requirement (the kernel's workgroups are short-lived
+ * and only ever wait for workgroups dispatched before them), so it shares the GPU with other work like any kernel. */
 int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
                         uint64_t *d_out_words, void *d_workspace, size_t workspace_bytes, void *stream);
 

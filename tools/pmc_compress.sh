@@ -11,6 +11,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_MFMA_I8" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
+  [ -n "$PMC_PASSES" ] && [ $i -gt $PMC_PASSES ] && break
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/$out/p$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --workload $wl $BENCH_EXTRA > $R/$out/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
@@ -20,7 +21,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(R+"/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k=row.get("Kernel_Name","")
-        short = "compress" if "compress_kernel" in k else ("scan" if "decode_scan" in k else ("expand" if "decode_expand" in k else None))
+        short = "compress" if "compress_tile_kernel" in k else ("scan" if "decode_scan" in k else ("expand" if "decode_expand" in k else None))
         if short: agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(R+"/summary.txt","w") as o:
     for k in agg:
