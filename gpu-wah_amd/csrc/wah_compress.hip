@@ -95,50 +95,89 @@ __device__ __forceinline__ void stage_prefetched(const Prefetch &p, u32 *lds, u3
     dst[lane + 192] = p.v[3];
 }
 
-// Classify + run detect + compact one staged segment (wave-private LDS), returns the number of words produced.
-//   classify  (kernels.cu:93-112): group = funnel shift of two staged words; zero / ones kinds by v_cmp, whose
-//             result IS the 64-lane mask.
-//   run ends  (kernels.cu:126-141 + the cross-warp merge of :188-229): a group does NOT end a run iff it is a
-//             fill and the next group of the segment has the same value.  "Same as next" is one DPP compare
-//             against the neighbouring lane (lane 63 is patched with lane 0 of the following step).  The group
-//             after the last one never matches, so every segment closes its last run (tests.cpp:166-172).
-//   compact   : run-end words go to LDS at rank = running count + mbcnt, written over the staged words (all of
-//             which are in registers by then), with the group position beside it (fill lengths are position
-//             differences, see final_words_to_regs).
-// The 16 steps are one generated, hand-scheduled block (csrc/classify_block.inc, tools/gen_classify_block.py):
-// 13.5 vector + 2 LDS instructions per step, software-pipelined by one step so that no hazard needs a wait state.
+// Classify + run detect + compact one segment, in three steps that the kernel interleaves for its two segments.
+//   regroup   (kernels.cu:72-79): group = funnel shift of two staged words, all 16 steps' groups into registers (the
+//             staging buffer is free again afterwards).
+//   pass 1    classify (kernels.cu:93-112) and run ends (kernels.cu:126-141 + the cross-warp merge of :188-229): a
+//             group does NOT end a run iff it is a fill and the next group of the segment has the same value:
+//               next   = lane l+1 (DPP wave_shl:1); lane 63 has no source lane and keeps the `old` operand, which a
+//                        wave_rol:1 of the NEXT step's register has loaded with that step's lane 0
+//               z      = (x ^ next) | ((x + 1) & 0x7FFFFFFE) is zero  <=>  x is 0 or 0x7FFFFFFF AND the next group equals it
+//               ends   = v_cmp_ne z, 0 -- the 64-lane mask comes out of the compare itself, into a scalar register pair
+//             The group after the last one never matches, so every segment closes its last run (tests.cpp:166-172).
+//             Result: 16 masks (32 scalar registers) and their population count = the words the segment compresses to
+//             -- all that the other workgroups need to know of it, so the kernel publishes it right here.
+//   pass 2    compact: run-end words go to LDS at rank = running count + v_mbcnt over the saved mask, with the group
+//             position beside them (fill lengths are position differences, see final_words_to_regs).
+// Passes 1 and 2 are generated, hand-scheduled blocks (csrc/classify_pass*.inc, tools/gen_classify_block.py).
 // The bitmap's last segment may be short (F5): the groups that do not exist are replaced by a literal -- literals
 // never merge, so the last real group closes its run and each of them becomes one entry BEHIND the real ones, which
 // is simply not counted.
 constexpr u32 kAbsentGroup = 0x2AAAAAAAu;
 
-__device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigned short *pos, u32 r, u32 lane_v, u32 nvalid,
-                                                bool &any_fill) {
-    // phase 1: all 16 LDS reads, then the funnel shifts: every staged word is in registers before the first
-    // compacted word overwrites the staging buffer
-    u32 x[kSteps + 1];
+struct SegGroups {
+    u32 x[kSteps]; // group 64 s + lane of the segment
+};
+// run ends of one segment, one word per lane: bit 15 - s says whether group 64 s + lane ends a run
+using SegEnds = u32;
+
+__device__ __forceinline__ void regroup(const u32 *sp, u32 r, u32 lane_v, u32 nvalid, SegGroups &g) {
+    // all 16 LDS reads, then the funnel shifts: every staged word is in registers before the buffer is reused
 #pragma unroll
     for (int s = 0; s < (int)kSteps; ++s) {
         const u32 lo = sp[62 * s];
         const u32 hi = sp[62 * s + 1];
-        x[s] = __builtin_amdgcn_alignbit(hi, lo, r) & kOnes31;
+        g.x[s] = __builtin_amdgcn_alignbit(hi, lo, r) & kOnes31;
     }
-    x[kSteps] = 0xFFFFFFFFu; // "group after the last one": a value no 31-bit group can equal
     if (nvalid != kSegGroups) {
+        u32 lv = lane_v; // opaque: keeps the sixteen position constants inside this cold branch
+        asm volatile("" : "+v"(lv));
 #pragma unroll
-        for (int s = 0; s < (int)kSteps; ++s) x[s] = 64u * s + lane_v < nvalid ? x[s] : kAbsentGroup;
+        for (int s = 0; s < (int)kSteps; ++s) g.x[s] = 64u * s + lv < nvalid ? g.x[s] : kAbsentGroup;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
 
-    // phase 2: one straight-line block of vector instructions per step.
-    //   next   : value of the following group = lane l+1 (DPP wave_shl:1); lane 63 has no source lane and keeps the
-    //            `old` operand, which a wave_rol:1 of the NEXT step's register has loaded with that step's lane 0
-    //   z      : (x ^ next) | ((x + 1) & 0x7FFFFFFE) is zero  <=>  x is 0 or 0x7FFFFFFF AND the next group equals it
-    //            <=>  the group does NOT end a run (kernels.cu:93-141 and the merge of :188-229 in three operations)
-    //   ends   : v_cmp_ne z, 0 -- the 64-lane mask comes out of the compare itself
-    //   rank   : v_mbcnt pair seeded with the running count (kept in a VECTOR register: no scalar work); count += v_bcnt pair
-    //   write  : every lane stores; lanes that end no run store to a dump slot (cheaper than masking EXEC)
-    u32 count_v = 0;
+// returns the number of run ends (absent groups of a short last segment included)
+__device__ __forceinline__ u32 classify_pass1(const SegGroups &g, u32 never, SegEnds &e) {
+    u32 cnt = 0, st;
+    u32 na, ta, nb, tb;
+    u32 f;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(f));
+    asm volatile(
+#include "classify_pass1.inc"
+        : [f] "+&v"(f), [cnt] "+&s"(cnt), [st] "=&s"(st), [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb)
+        : [x0] "v"(g.x[0]), [x1] "v"(g.x[1]), [x2] "v"(g.x[2]), [x3] "v"(g.x[3]), [x4] "v"(g.x[4]), [x5] "v"(g.x[5]), [x6] "v"(g.x[6]),
+          [x7] "v"(g.x[7]), [x8] "v"(g.x[8])
+        : "vcc", "scc");
+    asm volatile(
+#include "classify_pass1.inc"
+        : [f] "+&v"(f), [cnt] "+&s"(cnt), [st] "=&s"(st), [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb)
+        : [x0] "v"(g.x[8]), [x1] "v"(g.x[9]), [x2] "v"(g.x[10]), [x3] "v"(g.x[11]), [x4] "v"(g.x[12]), [x5] "v"(g.x[13]),
+          [x6] "v"(g.x[14]), [x7] "v"(g.x[15]), [x8] "v"(never)
+        : "vcc", "scc");
+    e = f;
+    return cnt;
+}
+
+// Some emitted word is a fill iff some group is one.  Fewer words than groups: certainly.  As many words as groups
+// (incompressible data): only fills of length 1 are possible, look for an all-zero / all-one group.
+__device__ __forceinline__ bool segment_has_fill(const SegGroups &g, u32 ends, u32 nvalid) {
+    if (ends != kSegGroups || nvalid != kSegGroups) return true;
+    u32 lo = g.x[0], hi = g.x[0];
+#pragma unroll
+    for (int s = 1; s < (int)kSteps; s += 2) {
+        lo = s + 1 < (int)kSteps ? min(lo, min(g.x[s], g.x[s + 1])) : min(lo, g.x[s]);
+        hi = s + 1 < (int)kSteps ? max(hi, max(g.x[s], g.x[s + 1])) : max(hi, g.x[s]);
+    }
+    return __ballot(lo == 0u || hi == kOnes31) != 0;
+}
+
+__device__ __forceinline__ void classify_pass2(const SegGroups &g, SegEnds e, u32 *lds, unsigned short *pos, u32 lane_v) {
+    // mask : the step's run ends come back out of the flag word, top bit first (v_add_co f, f, f: the carry is the mask)
+    // rank : v_mbcnt pair seeded with the running count (kept in a VECTOR register: no scalar work); count += v_bcnt pair
+    // write: every lane stores; lanes that end no run store to a dump slot (cheaper than masking EXEC)
+    u32 count_v;
     asm volatile("v_mov_b32 %0, 0" : "=v"(count_v));
     // LDS byte addresses: value k at vbase + 4 k, its position at pbase + 2 k; k = kStageWords is the dump slot
     const u32 vbase = (u32)(uintptr_t)(lds_u32_ptr)lds;
@@ -148,27 +187,19 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
     static_assert(kStageWords == 0x400, "dump slot literal");
     u32 na, ta, nb, tb, ps;
     const u32 lane2 = lane_v * 0x10001u; // the lane id in both halves: position words are built two at a time
+    u32 f = e << 16;                     // step 0 at the top
     asm volatile(
-#include "classify_block.inc"
-        : [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)
-        : [x0] "v"(x[0]), [x1] "v"(x[1]), [x2] "v"(x[2]), [x3] "v"(x[3]), [x4] "v"(x[4]), [x5] "v"(x[5]), [x6] "v"(x[6]), [x7] "v"(x[7]),
-          [x8] "v"(x[8]), [x9] "v"(x[9]), [x10] "v"(x[10]), [x11] "v"(x[11]), [x12] "v"(x[12]), [x13] "v"(x[13]), [x14] "v"(x[14]),
-          [x15] "v"(x[15]), [x16] "v"(x[16]), [ln2] "v"(lane2), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)
+#include "classify_pass2_a.inc"
+        : [f] "+&v"(f), [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)
+        : [x0] "v"(g.x[0]), [x1] "v"(g.x[1]), [x2] "v"(g.x[2]), [x3] "v"(g.x[3]), [x4] "v"(g.x[4]), [x5] "v"(g.x[5]), [x6] "v"(g.x[6]),
+          [x7] "v"(g.x[7]), [ln2] "v"(lane2), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)
         : "vcc", "memory");
-    u32 count = uniform32(count_v);
-    // Some emitted word is a fill iff some group is one.  Fewer words than groups: certainly.  As many words as
-    // groups (incompressible data): only fills of length 1 are possible, look for an all-zero / all-one group.
-    any_fill = true;
-    if (count == kSegGroups && nvalid == kSegGroups) {
-        u32 lo = x[0], hi = x[0];
-#pragma unroll
-        for (int s = 1; s < (int)kSteps; s += 2) {
-            lo = s + 1 < (int)kSteps ? min(lo, min(x[s], x[s + 1])) : min(lo, x[s]);
-            hi = s + 1 < (int)kSteps ? max(hi, max(x[s], x[s + 1])) : max(hi, x[s]);
-        }
-        any_fill = __ballot(lo == 0u || hi == kOnes31) != 0;
-    }
-    return count - (kSegGroups - nvalid);
+    asm volatile(
+#include "classify_pass2_b.inc"
+        : [f] "+&v"(f), [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)
+        : [x0] "v"(g.x[8]), [x1] "v"(g.x[9]), [x2] "v"(g.x[10]), [x3] "v"(g.x[11]), [x4] "v"(g.x[12]), [x5] "v"(g.x[13]),
+          [x6] "v"(g.x[14]), [x7] "v"(g.x[15]), [ln2] "v"(lane2), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)
+        : "vcc", "memory");
 }
 
 // ===========================================================================
@@ -185,9 +216,9 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
 // that waits at the barrier issues no instructions (the SIMDs of this kernel are bound by instruction issue).
 //
 // Row scan (replaces thrust::exclusive_scan + the two blocking 8-byte reads of compress.cu:133-157).
-//   granule[t]           u32 {epoch:17, words:15} of tile t, published as soon as the tile's words are counted
-//   slot[s][0]           u64 {epoch:17, words:47}: words in front of superrow s  (superrow = kSuperRows rows)
-//   slot[s][1 + k]       u64 {epoch:17, words:47}: words of row k of superrow s  (row = kRowTiles tiles)
+//   granule[t]           u32 {epoch:16, words:16} of tile t, published as soon as the tile's words are counted
+//   slot[s][0]           u64 {epoch:16, words:48}: words in front of superrow s  (superrow = kSuperRows rows)
+//   slot[s][1 + k]       u64 {epoch:16, words:48}: words of row k of superrow s  (row = kRowTiles tiles)
 // (scan area = one block per superrow: its 64 x 256 granules, then its 65 slots -- every entry has the same address and
 //  the same meaning whatever the size of the bitmap, so a workspace can serve bitmaps of different sizes in turn)
 // Tile (row r, index i) adds up, in ONE round trip of three loads per lane:
@@ -201,15 +232,15 @@ __device__ __forceinline__ u32 classify_compact(const u32 *sp, u32 *lds, unsigne
 // Epochs: the workspace is never cleared.  Every launch stamps what it publishes with the launch epoch kept in the
 // control block (read by every workgroup at its start, advanced by the LAST tile once its scan is complete -- by
 // then every other tile has published, hence started).  A zeroed workspace is epoch 0 = "nothing valid".  When
-// the 17-bit epoch is used up, the next launch has tile 0 clear the scan area while the others wait for it.
+// the 16-bit epoch is used up, the next launch has tile 0 clear the scan area while the others wait for it.
 // ===========================================================================
 constexpr u32 kTileWaves = (u32)kCompressTileWaves;
 constexpr u32 kRowTiles = 256;             // granules per row: one 16-byte load per lane
 constexpr u32 kSuperRows = 64;             // rows per superrow: one 8-byte load per lane
 constexpr u32 kWaveSegs = (u32)kCompressWaveSegs;
-constexpr u32 kCountBits = 15;             // words of a tile <= 8 * 2 * 1024
+constexpr u32 kCountBits = 16;             // words of a tile <= 8 * 4 * 1024 (stored minus nothing: 2^15 fits 16 bits)
 constexpr u32 kCountMask = (1u << kCountBits) - 1u;
-constexpr u32 kSlotShift = 47;             // u64 slots: value in the low 47 bits
+constexpr u32 kSlotShift = 48;             // u64 slots: value in the low 48 bits
 constexpr u64 kSlotMask = (1ull << kSlotShift) - 1ull;
 static_assert(kTileWaves * kWaveSegs * kSegGroups <= kCountMask, "tile count must fit the granule");
 static_assert(kEpochWrap < (1u << (32 - kCountBits)), "epochs must fit the granule");
@@ -217,6 +248,7 @@ static_assert(kRowSlots == kSuperRows + 1, "slot layout");
 static_assert(kSlotShift - 32 == kCountBits, "the high half of a slot carries its epoch where a granule does");
 static_assert(kScanBlockWords >= kSuperRows * kRowTiles + 2 * kRowSlots && kScanSlotsAt == kSuperRows * kRowTiles, "scan block layout");
 
+constexpr u32 kDirectLanes = 6; // up to this many lanes with missing entries are simply read again
 constexpr int kAuxSc1 = 16; // buffer load cache policy: sc1 = agent scope (served past the XCD-private caches)
 
 struct TileScan {
@@ -314,7 +346,7 @@ __device__ __forceinline__ void emit_regs(const CompressArgs &a, u64 base, u32 c
 }
 
 template <bool kPair, bool kAligned>
-__global__ __launch_bounds__(kTileWaves * 64, 6) void compress_tile_kernel(const CompressArgs a) {
+__global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 3 ? 6 : 4) void compress_tile_kernel(const CompressArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_out[kTileWaves][kOutWords];
     __shared__ unsigned short s_pos[kTileWaves][kPosEntries];
     __shared__ u32 s_count[kTileWaves];
@@ -324,7 +356,7 @@ __global__ __launch_bounds__(kTileWaves * 64, 6) void compress_tile_kernel(const
     const u32 lane = lane_id();
     const u32 wave = wave_id();
     const u32 tile = blockIdx.x;
-    const u32 seg0 = (tile * kTileWaves + wave) * kWaveSegs; // this wave's segments: seg0, seg0 + 1
+    const u32 seg0 = (tile * kTileWaves + wave) * kWaveSegs; // this wave's segments: seg0 .. seg0 + kWaveSegs - 1
 #ifdef WAH_DIAG
     u64 dg_t[6];
     u32 dg_polls = 0;
@@ -384,19 +416,28 @@ __global__ __launch_bounds__(kTileWaves * 64, 6) void compress_tile_kernel(const
     const u32 *const sp = stage + ((31u * lane) >> 5);
     u32 out[kWaveSegs][16];
     u32 cnt[kWaveSegs];
+    SegGroups grp[kWaveSegs];
+    SegEnds ends[kWaveSegs];
+    u32 nval[kWaveSegs];
+    u32 never;
+    asm volatile("v_mov_b32 %0, -1" : "=v"(never)); // "group after the last one": a value no 31-bit group can equal
     Prefetch pre, pre2; // pre2: pair mode only (wah_bitop_device), the second bitmap's words
     if (seg0 < a.n_segments) {
         prefetch_segment<kAligned>(a.in, a, seg0, lane, pre);
         if (kPair) prefetch_segment<kAligned>(a.in2, a, seg0, lane, pre2);
     }
+    // ---- pass 1 of both segments: nothing but their word counts, which is all the other workgroups wait for.  Every
+    //      tile behind this one waits for that count, so this part runs at raised priority; what follows the publication
+    //      (pass 2, final words) has the round trip of the sweep to hide in and runs at the lowest ------------------------
+    if ((a.tune & 3u) != 1u) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (u32 j = 0; j < kWaveSegs; ++j) {
         const u32 seg = seg0 + j;
         cnt[j] = 0;
+        nval[j] = kSegGroups;
         if (seg < a.n_segments) {
             if (kPair) combine_pair(pre, pre2, a.op);
             stage_prefetched(pre, stage, lane);
-            if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
             // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             if (j == 0) DG(1);
@@ -405,13 +446,9 @@ __global__ __launch_bounds__(kTileWaves * 64, 6) void compress_tile_kernel(const
                 prefetch_segment<kAligned>(a.in, a, seg + 1, lane, pre);
                 if (kPair) prefetch_segment<kAligned>(a.in2, a, seg + 1, lane, pre2);
             }
-            const u32 nvalid = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
-            bool any_fill = false;
-            cnt[j] = classify_compact(sp, stage, pos, r, lane, nvalid, any_fill);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            final_words_to_regs(stage, pos, lane, cnt[j], any_fill, out[j]);
-            // the buffer is staged over next: order these reads before those writes
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            nval[j] = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
+            regroup(sp, r, lane, nval[j], grp[j]);
+            cnt[j] = classify_pass1(grp[j], never, ends[j]) - (kSegGroups - nval[j]);
         }
     }
     u32 count = 0;
@@ -421,27 +458,55 @@ __global__ __launch_bounds__(kTileWaves * 64, 6) void compress_tile_kernel(const
     DG(2);
     __syncthreads();
     DG(3);
+    if ((a.tune & 3u) != 1u && wave != 0) __builtin_amdgcn_s_setprio(0);
 
+    // ---- wave 0: the tile's count goes out, the sweep of the others' counts is issued --------------------------------
+    const ScanGeom g = scan_geom(tile);
+    u32 *const block = a.gen_desc + (u64)g.sup * kScanBlockWords;
+    TileScan poll = {};
+    u32 total = 0;
     if (wave == 0) {
-        // ---- the tile's count, then its offset -------------------------------------------------------------------
         const u32 mine = lane < kTileWaves ? s_count[lane] : 0u;
         const u32 incl = wave_scan_incl32(mine);
         if (lane < kTileWaves) s_prefix[lane] = incl - mine;
-        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        const ScanGeom g = scan_geom(tile);
-        u32 *const block = a.gen_desc + (u64)g.sup * kScanBlockWords;
+        total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         if (lane == 0)
             __hip_atomic_store(block + (g.row - g.row0) * kRowTiles + g.idx, (epoch << kCountBits) | total, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+        // One round trip of three loads per lane, issued now that the count is out and collected after pass 2: by
+        // then the tiles dispatched before this one have normally published theirs.
+        scan_issue(a, g, lane, true, g.has_prev, true, poll);
+        if ((a.tune & 3u) != 1u) __builtin_amdgcn_s_setprio(0);
+#ifdef WAH_DIAG
+        if (a.tune == 77u) { // time line mode: how long does the sweep itself take?
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            DG(5);
+        }
+#endif
+    }
 
-        // One round trip of three loads per lane, issued now that the count is out: by the time they are served, the
-        // tiles dispatched before this one have normally published theirs.  If something is still missing, the wave
-        // does NOT sweep again and again (hundreds of waiting tiles re-reading 2.5 KB each every microsecond is traffic
-        // of the order of the bitmap's): it spins on ONE word, the missing entry with the highest tile number -- the one
-        // that will be published last -- and sweeps again when that one is there.
+    // ---- pass 2 of both segments: compaction in LDS, final words into registers -------------------------------------
+#pragma unroll
+    for (u32 j = 0; j < kWaveSegs; ++j) {
+        if (seg0 + j < a.n_segments) {
+            if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
+            classify_pass2(grp[j], ends[j], stage, pos, lane);
+            const bool any_fill = segment_has_fill(grp[j], cnt[j] + (kSegGroups - nval[j]), nval[j]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            final_words_to_regs(stage, pos, lane, cnt[j], any_fill, out[j]);
+            // the buffer is written again next: order these reads before those writes
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+
+    if (wave == 0) {
+        // ---- the tile's offset ---------------------------------------------------------------------------------------
+        // If a few entries of the sweep are still missing (the nearest predecessors), only their lanes read again.  If
+        // many are (a tile of an XCD that runs ahead of the others), the wave does NOT sweep again and again -- hundreds
+        // of waiting tiles re-reading 2.5 KB each every microsecond is traffic of the order of the bitmap's: it spins on
+        // ONE word, the missing entry with the highest tile number, the one that will be published last, and sweeps
+        // again when that one is there.
         bool need_a = true, need_b = g.has_prev, need_c = true;
-        TileScan poll = {};
-        scan_issue(a, g, lane, need_a, need_b, need_c, poll);
         u32 sum_a = 0, sum_b = 0;
         u64 sum_c = 0;
         u32 spins = 0;
@@ -484,6 +549,22 @@ __global__ __launch_bounds__(kTileWaves * 64, 6) void compress_tile_kernel(const
                 }
             }
             if (!(need_a || need_b || need_c)) break;
+            if (++spins > kMaxSpins) {
+                if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
+                break;
+            }
+            const u32 n_bad = (u32)__builtin_popcountll(ba) + (u32)__builtin_popcountll(bb) + (u32)__builtin_popcountll(bc);
+            if (n_bad <= kDirectLanes) {
+                // a few stragglers among the nearest predecessors (the usual case): read just those lanes' entries again
+                __builtin_amdgcn_s_sleep(4);
+                if (need_a && bad_a != 0u) scan_issue(a, g, lane, true, false, false, poll);
+                if (need_b && bad_b != 0u) scan_issue(a, g, lane, false, true, false, poll);
+                if (need_c && bad_c) scan_issue(a, g, lane, false, false, true, poll);
+#ifdef WAH_DIAG
+                ++dg_polls;
+#endif
+                continue;
+            }
             // the word to wait for: {epoch, ...} in its top bits, whichever array it belongs to
             const u32 *target;
             if (need_a) {
@@ -537,7 +618,14 @@ __global__ __launch_bounds__(kTileWaves * 64, 6) void compress_tile_kernel(const
     }
     __syncthreads();
 #ifdef WAH_DIAG
-    if (wave == 0 && lane == 0 && (tile & 63u) == 0u) { // a sample: the atomics must not become the bottleneck
+    if (wave == 0 && lane == 0 && a.seg_offsets && a.tune == 77u) { // per-tile time line (tools/tile_timeline.py)
+        a.seg_offsets[(u64)tile * 8 + 0] = dg_t[0]; // start
+        a.seg_offsets[(u64)tile * 8 + 1] = dg_t[3]; // counts known (barrier 1 passed) = publish
+        a.seg_offsets[(u64)tile * 8 + 2] = dg_t[5]; // first sweep returned
+        a.seg_offsets[(u64)tile * 8 + 3] = dg_t[4]; // offset known
+        a.seg_offsets[(u64)tile * 8 + 4] = dg_polls;
+    }
+    if (wave == 0 && lane == 0 && tile % 67u == 0u) { // a sample: the atomics must not become the bottleneck
         unsigned long long *d = reinterpret_cast<unsigned long long *>(a.ctrl + 192);
         atomicAdd(d + 0, (unsigned long long)(dg_t[1] - dg_t[0])); // loads -> staged
         atomicAdd(d + 1, (unsigned long long)(dg_t[2] - dg_t[1])); // classify
@@ -546,9 +634,19 @@ __global__ __launch_bounds__(kTileWaves * 64, 6) void compress_tile_kernel(const
         atomicAdd(d + 4, (unsigned long long)dg_polls);
         atomicAdd(d + 5, 1ull);
         atomicAdd(d + 6, (unsigned long long)(__builtin_amdgcn_s_memrealtime() - dg_t[0]));
+        u32 xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 7u;
+        atomicAdd(d + 8 + xcc, (unsigned long long)(dg_t[4] - dg_t[3]));  // scan (incl. pass 2) by XCD
+        atomicAdd(d + 16 + xcc, (unsigned long long)dg_polls);            // re-polls by XCD
+        atomicAdd(d + 24 + xcc, 1ull);                                     // sampled tiles by XCD
+        if (xcc != (tile & 7u)) atomicAdd(d + 7, 1ull);                    // tiles NOT on XCD blockIdx % 8
     }
 #endif
 
+#ifdef WAH_DIAG
+    if (a.seg_offsets && a.tune == 77u) return; // time line mode: the index buffer holds the stamps
+#endif
     // ---- the parked words to their place ---------------------------------------------------------------------------
     u64 base = uniform64(s_base) + uniform32(s_prefix[wave]);
 #pragma unroll

@@ -35,11 +35,17 @@ constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity
 constexpr uint32_t kErrStream = 4u;      // malformed compressed stream
 constexpr uint32_t kErrWorkspace = 8u;   // compress workspace neither zeroed nor left by an earlier launch
 constexpr uint32_t kWorkspaceMagic = 0x57414832u; // "WAH2"
-constexpr uint32_t kEpochWrap = (1u << 17) - 1u;  // stored epoch >= this: the next launch clears the scan area first
+constexpr uint32_t kEpochWrap = (1u << 16) - 1u;  // stored epoch >= this: the next launch clears the scan area first
 
 // ---- compress geometry: one wavefront owns one segment, a workgroup (tile) kCompressTileWaves of them ------------
-constexpr int kCompressTileWaves = 8;
-constexpr int kCompressWaveSegs = 2; // segments a wavefront compresses one after the other
+#ifndef WAH_TILE_WAVES
+#define WAH_TILE_WAVES 8
+#endif
+constexpr int kCompressTileWaves = WAH_TILE_WAVES;
+#ifndef WAH_WAVE_SEGS
+#define WAH_WAVE_SEGS 4
+#endif
+constexpr int kCompressWaveSegs = WAH_WAVE_SEGS; // segments a wavefront compresses one after the other
 // scan area of the compress kernel (see compress_tile_kernel): one block per superrow of 64 rows x 256 tiles
 constexpr uint32_t kRowSlots = 65;                 // u64 slots of a superrow: words in front of it, words of each of its rows
 constexpr uint32_t kScanSlotsAt = 64 * 256;        // 32-bit words: the slots follow the superrow's granules

@@ -25,10 +25,13 @@ for kind in sys.argv[1:] or ["sparse", "dense", "clustered"]:
     comp.run(d)
     ev[1].record()
     comp.status()
-    acc = comp.workspace[768:768 + 64].view(torch.int64).cpu().tolist()
+    acc = comp.workspace[768:1024].view(torch.int64).cpu().tolist()
     tiles = max(acc[5], 1)
     print(f"--- {kind}: {tiles} tiles, launch {ev[0].elapsed_time(ev[1]):.3f} ms (diag build), WAH_TUNE={os.environ.get('WAH_TUNE', '0')}")
     for i in (0, 1, 2, 3, 6):
         print(f"   {names[i]:18s} {acc[i] / tiles / 100.0:7.2f} us/tile")
-    print(f"   re-polls per tile  {acc[4] / tiles:7.2f}")
+    print(f"   re-polls per tile  {acc[4] / tiles:7.2f}   tiles not on XCD blockIdx%8: {acc[7]}")
+    print("   by XCD: scan us   " + " ".join(f"{acc[8 + x] / max(acc[24 + x], 1) / 100.0:6.2f}" for x in range(8)))
+    print("   by XCD: re-polls  " + " ".join(f"{acc[16 + x] / max(acc[24 + x], 1):6.2f}" for x in range(8)))
+    print("   by XCD: tiles     " + " ".join(f"{acc[24 + x]:6d}" for x in range(8)))
     del comp, d
