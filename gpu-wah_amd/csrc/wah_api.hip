@@ -38,6 +38,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 struct CompressLayout {
     uint64_t n_groups, n_segments, n_tiles;
+    uint32_t wave_segs;
     size_t ctrl_off, desc_off, total;
 };
 
@@ -46,8 +47,10 @@ CompressLayout compress_layout(uint64_t n_words) {
     CompressLayout l;
     l.n_groups = wah_max_compressed_words(n_words);
     l.n_segments = ceil_div(l.n_groups, wah::kSegGroups);
-    l.n_tiles = ceil_div(l.n_segments, (uint64_t)(wah::kCompressTileWaves * wah::kCompressWaveSegs));
-    const uint64_t blocks = l.n_tiles / wah::kScanBlockTiles + 1;
+    l.wave_segs = wah::compress_wave_segs(l.n_segments);
+    l.n_tiles = ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * l.wave_segs);
+    // sized for the shortest tiles: a workspace serves any smaller bitmap too
+    const uint64_t blocks = ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves) / wah::kScanBlockTiles + 1;
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
     l.total = round256(l.desc_off + blocks * wah::kScanBlockWords * sizeof(uint32_t));
@@ -341,6 +344,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     a.n_words = n_words;
     a.n_segments = (uint32_t)l.n_segments;
     a.n_tiles = (uint32_t)l.n_tiles;
+    a.wave_segs = l.wave_segs;
     a.fast_segments = aligned16(d_in) ? 1u : 0u;
     a.full_segments = (uint32_t)(n_words / wah::kSegWords);
     a.tail_bytes = (uint32_t)(n_words % wah::kSegWords) * 4u;

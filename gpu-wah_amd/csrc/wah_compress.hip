@@ -237,12 +237,11 @@ __device__ __forceinline__ void classify_pass2(const SegGroups &g, SegEnds e, u3
 constexpr u32 kTileWaves = (u32)kCompressTileWaves;
 constexpr u32 kRowTiles = 256;             // granules per row: one 16-byte load per lane
 constexpr u32 kSuperRows = 64;             // rows per superrow: one 8-byte load per lane
-constexpr u32 kWaveSegs = (u32)kCompressWaveSegs;
 constexpr u32 kCountBits = 16;             // words of a tile <= 8 * 4 * 1024 (stored minus nothing: 2^15 fits 16 bits)
 constexpr u32 kCountMask = (1u << kCountBits) - 1u;
 constexpr u32 kSlotShift = 48;             // u64 slots: value in the low 48 bits
 constexpr u64 kSlotMask = (1ull << kSlotShift) - 1ull;
-static_assert(kTileWaves * kWaveSegs * kSegGroups <= kCountMask, "tile count must fit the granule");
+static_assert(kTileWaves * kCompressMaxWaveSegs * kSegGroups <= kCountMask, "tile count must fit the granule");
 static_assert(kEpochWrap < (1u << (32 - kCountBits)), "epochs must fit the granule");
 static_assert(kRowSlots == kSuperRows + 1, "slot layout");
 static_assert(kSlotShift - 32 == kCountBits, "the high half of a slot carries its epoch where a granule does");
@@ -345,8 +344,11 @@ __device__ __forceinline__ void emit_regs(const CompressArgs &a, u64 base, u32 c
     }
 }
 
-template <bool kPair, bool kAligned>
-__global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 3 ? 6 : 4) void compress_tile_kernel(const CompressArgs a) {
+// kWaveSegs: segments a wavefront compresses one after the other (the tile = kTileWaves x kWaveSegs segments).  Large
+// bitmaps take 5: a wave's four idle stretches (first load, barrier, offset, store drain) are paid once per five
+// segments, and 16 waves per CU keep 80 segments in flight.  Small bitmaps take 1 or 2: more, shorter tiles.
+template <bool kPair, bool kAligned, u32 kWaveSegs>
+__global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compress_tile_kernel(const CompressArgs a) {
     __shared__ __attribute__((aligned(16))) u32 s_out[kTileWaves][kOutWords];
     __shared__ unsigned short s_pos[kTileWaves][kPosEntries];
     __shared__ u32 s_count[kTileWaves];
@@ -662,14 +664,31 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 3 ? 6 : 4) void compr
 
 } // namespace
 
+template <bool kPair, bool kAligned>
+static void launch_tiles(const CompressArgs &a, hipStream_t s) {
+    const dim3 grid(a.n_tiles), block(kTileWaves * 64);
+    switch (a.wave_segs) {
+    case 1: hipLaunchKernelGGL((compress_tile_kernel<kPair, kAligned, 1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((compress_tile_kernel<kPair, kAligned, 2>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((compress_tile_kernel<kPair, kAligned, (u32)kCompressMaxWaveSegs>), grid, block, 0, s, a); break;
+    }
+}
+
 hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {
     if (a.in2)
-        hipLaunchKernelGGL((compress_tile_kernel<true, true>), dim3(a.n_tiles), dim3(kTileWaves * 64), 0, s, a);
+        launch_tiles<true, true>(a, s);
     else if (a.fast_segments)
-        hipLaunchKernelGGL((compress_tile_kernel<false, true>), dim3(a.n_tiles), dim3(kTileWaves * 64), 0, s, a);
+        launch_tiles<false, true>(a, s);
     else // input only 4-byte aligned: dword loads
-        hipLaunchKernelGGL((compress_tile_kernel<false, false>), dim3(a.n_tiles), dim3(kTileWaves * 64), 0, s, a);
+        launch_tiles<false, false>(a, s);
     return hipGetLastError();
+}
+
+// segments per wavefront for a bitmap of n_segments: enough tiles to occupy the chip first, long tiles after that
+uint32_t compress_wave_segs(uint64_t n_segments) {
+    if (n_segments <= 6144) return 1;  // 256 CUs x 3 workgroups x 8 waves: one round of one-segment waves
+    if (n_segments <= 24576) return 2;
+    return (uint32_t)kCompressMaxWaveSegs;
 }
 
 // wah_bitop_device: both operands must have expanded to the bitmap length the caller named, without errors of their own

@@ -42,10 +42,8 @@ constexpr uint32_t kEpochWrap = (1u << 16) - 1u;  // stored epoch >= this: the n
 #define WAH_TILE_WAVES 8
 #endif
 constexpr int kCompressTileWaves = WAH_TILE_WAVES;
-#ifndef WAH_WAVE_SEGS
-#define WAH_WAVE_SEGS 4
-#endif
-constexpr int kCompressWaveSegs = WAH_WAVE_SEGS; // segments a wavefront compresses one after the other
+constexpr int kCompressMaxWaveSegs = 5; // segments a wavefront compresses one after the other: 1, 2 or this (by bitmap size)
+uint32_t compress_wave_segs(uint64_t n_segments);
 // scan area of the compress kernel (see compress_tile_kernel): one block per superrow of 64 rows x 256 tiles
 constexpr uint32_t kRowSlots = 65;                 // u64 slots of a superrow: words in front of it, words of each of its rows
 constexpr uint32_t kScanSlotsAt = 64 * 256;        // 32-bit words: the slots follow the superrow's granules
@@ -63,7 +61,8 @@ struct CompressArgs {
     uint32_t op;           // ... with WAH_OP_AND / OR / XOR / ANDNOT
     uint64_t n_words;
     uint32_t n_segments;          // ceil(G / 1024)
-    uint32_t n_tiles;             // ceil(n_segments / (kCompressTileWaves * kCompressWaveSegs))
+    uint32_t wave_segs;           // segments per wavefront of this launch (compress_wave_segs)
+    uint32_t n_tiles;             // ceil(n_segments / (kCompressTileWaves * wave_segs))
     uint32_t fast_segments;       // 1: input 16-byte aligned -> prefetched buffer loads; 0: scalar staging
     uint32_t last_segment_groups; // groups of the last segment (1..1024)
     uint32_t full_segments;       // n_words / 992: segments that lie wholly inside the bitmap
