@@ -1,29 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the WAH hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--workload sparse|clustered|dense|columns]
+
+N = 1 runs in this process.  N > 1: when the process was not started by a launcher (no WORLD_SIZE in the environment)
+it starts N fresh ranks itself -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+... bench.py <same arguments>` -- BEFORE it touches a GPU, relays rank 0's JSON line and exits with the ranks' status;
+started by a launcher it checks that WORLD_SIZE equals --gpus and refuses to run otherwise.  It never prints a line
+for fewer GPUs than were asked for.
 
 One "step" = one pass of the hot path over synthetic bitmaps already resident in HBM:
-  sparse / clustered / dense : compress() then decompress() of one 1 GiB bitmap
-                               (BASELINE.json configs[1] / [2] / [3]; default: sparse = configs[1])
-  columns                    : compress() of this rank's share of many independent 128 MiB columns
-                               (configs[4]; column c belongs to rank c mod N)
-`value` is uncompressed input bytes per second through the step, whole job: with N > 1 every rank works on its own
-bitmap(s) -- columns are unrelated, there is no collective on the data path -- so scaling is "weak" (fixed work per
-GPU); the time is the maximum over ranks of a barrier-bracketed wall clock.
+  sparse / clustered / dense : compress() then decompress() of one 1 GiB bitmap per GPU
+                               (BASELINE.json configs[1] / [2] / [3]; default: sparse = configs[1]); every rank has its
+                               own bitmap, so per-GPU work is fixed: "scaling": "weak"
+  columns                    : compress() of 1024 independent 128 MiB columns (configs[4]), column c on rank c mod N,
+                               resident in HBM, compressed in batches of up to 128 columns per launch; the total is
+                               fixed, so "scaling": "strong"
+`value` is uncompressed input bytes per second through the step, whole job; the time is the maximum over ranks of a
+barrier-bracketed wall clock.  There is no collective on the data path and RCCL is not initialised at all: the two
+scalars of the report (bytes, slowest rank's time) and the barriers go over gloo on 127.0.0.1.
 
 The JSON line also carries
-  roofline     : the dominant kernel (compress_kernel) against the HBM roof.  achieved = algorithmic bytes per launch
-                 (4N + 4C) / its average launch duration, measured here with device events on the
-                 stream it runs on.  `traffic` = HBM bytes per launch from the PMC passes recorded in
-                 profiles/traffic.json (rocprofv3 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes + WRITE_SIZE).
+  roofline     : the dominant kernel (compress_tile_kernel) against the HBM roof.  achieved = algorithmic bytes per
+                 launch (4N + 4C) / its average launch duration inside the round trip, measured
+                 here with device events on the stream it runs on; launch_ms_isolated = the same kernel in a
+                 compress-only loop (in the round trip it starts while the expand kernel's 1 GiB of writes is still
+                 draining from the memory-side cache).  `traffic` = HBM bytes per launch from the PMC passes recorded
+                 in profiles/traffic.json (rocprofv3 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes + WRITE_SIZE):
+                 a number replayed from that profile, not counted in this run ("traffic_measured_in_run": false).
   cpu_baseline : the CPU oracle (a port of the reference algorithm -- the reference has no CPU path and its CUDA
                  cannot run here) timed on a bounded sample of the same workload on this box's host cores.
+
+WAH_BENCH_REHEARSE=1   : rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share the cards).
+WAH_BENCH_REHEARSE=cpu : rehearsal without any GPU: launcher, rendezvous, sharding, reductions and the JSON line with
+                         empty steps.  Either way the line says "rehearsal" and its numbers mean nothing.
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,18 +48,21 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
+COLUMN_WORDS = 33554400  # 128 MiB - 128 B: 33825 whole 992-word segments
+COLUMNS_TOTAL = 1024     # BASELINE.json configs[4]
+COLUMNS_PER_LAUNCH = 128  # 16 GiB of columns per launch: input + worst-case output of a batch stay far below HBM
 
 WORKLOADS = {
     # name: (generator, parameter, description)
     "sparse": ("uniform", 0.01, "1 GiB uniform p=0.01 bitmap, compress+decompress round trip (BASELINE configs[1])"),
     "clustered": ("clustered", 4096, "1 GiB clustered runs (mean 4096 bits), compress+decompress (BASELINE configs[2])"),
     "dense": ("uniform", 0.5, "1 GiB uniform p=0.5 bitmap, all literals, compress+decompress (BASELINE configs[3])"),
-    "columns": (None, None, "independent 128 MiB bitmap columns (sparse/clustered/dense in turn), compress, column c on "
-                            "rank c mod N (BASELINE configs[4])"),
+    "columns": (None, None, "1024 independent 128 MiB bitmap columns (sparse/clustered/dense in turn), compress, column c "
+                            "on rank c mod N (BASELINE configs[4])"),
 }
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -51,16 +70,67 @@ def parse():
     ap.add_argument("--workload", default="sparse", choices=sorted(WORKLOADS))
     ap.add_argument("--words", type=int, default=None,
                     help="bitmap size in 32-bit words (default 268435200 = 270600 whole segments = 1 GiB - 1 KiB; "
-                         "columns: 33554400 = 128 MiB)")
-    ap.add_argument("--columns", type=int, default=None, help="columns workload: total number of columns (default 64 per GPU)")
-    ap.add_argument("--per-column-launches", action="store_true", help="columns workload: one launch per column instead of one per step")
+                         f"columns: {COLUMN_WORDS} = 128 MiB)")
+    ap.add_argument("--columns", type=int, default=None, help=f"columns workload: total number of columns (default {COLUMNS_TOTAL})")
+    ap.add_argument("--columns-per-launch", type=int, default=COLUMNS_PER_LAUNCH)
+    ap.add_argument("--per-column-launches", action="store_true", help="columns workload: one launch per column")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="size of the CPU-baseline sample (default: the whole 1 GiB bitmap, about 10 s of host work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1337)
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when this process starts the ranks itself")
+    ap.add_argument("--dry-launch", action="store_true", help="print the launcher command this call would run and exit")
+    return ap.parse_args(argv)
 
 
-def timed_steps(step, steps, warmup, dist=None, device=None, reduce_device=None):
+# ----------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks
+# ----------------------------------------------------------------------------------------------------------------
+def launcher_command(args, argv):
+    """The command that starts args.gpus ranks of this script (one per GPU) on this node."""
+    port = args.master_port or (29500 + os.getpid() % 2000)
+    passed = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + passed
+
+
+def launch_ranks(args, argv):
+    """Parent of an N > 1 run: no GPU call is made in this process.  Returns the exit status."""
+    cmd = launcher_command(args, argv)
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": cmd, "n_gpus": args.gpus}), flush=True)
+        return 0
+    rehearse = os.environ.get("WAH_BENCH_REHEARSE")
+    if not rehearse:
+        import torch  # device_count() does not initialise the GPU
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible; refusing to report a smaller run "
+                  f"(WAH_BENCH_REHEARSE=1 rehearses the multi-rank path on shared cards)", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write(proc.stdout)
+        print(f"bench.py: the {args.gpus}-rank run failed (exit {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    if json.loads(line).get("n_gpus") != args.gpus:
+        print("bench.py: the ranks reported a different GPU count than requested", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# measurement
+# ----------------------------------------------------------------------------------------------------------------
+def timed_steps(step, steps, warmup, dist=None, device=None):
     """The measurement contract: W untimed steps, then exactly K steps between two barriers (+ device syncs), and
     the MAX over ranks of the wall time.  `dist` is torch.distributed (or None), `device` a CUDA device (or None on
     the CPU rehearsal)."""
@@ -83,8 +153,7 @@ def timed_steps(step, steps, warmup, dist=None, device=None, reduce_device=None)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        where = reduce_device if reduce_device is not None else (device if device is not None else "cpu")
-        t = torch.tensor([elapsed], dtype=torch.float64, device=where)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
@@ -120,92 +189,129 @@ def load_traffic(workload):
         return None
 
 
-def main():
-    args = parse()
+def column_plan(n_columns, rank, world, per_launch):
+    """This rank's columns (c with c % world == rank) and how they are cut into launches."""
+    mine = list(range(rank, n_columns, world))
+    batches = [mine[i:i + per_launch] for i in range(0, len(mine), max(per_launch, 1))]
+    return mine, batches
+
+
+def init_ranks(rank, world):
+    """Control plane of an N > 1 run: gloo on 127.0.0.1 (barriers + two scalars).  RCCL is not used."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def run_rank(args):
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    rehearse = os.environ.get("WAH_BENCH_REHEARSE")
+    cpu_only = rehearse == "cpu"
+    if not cpu_only and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # WAH_BENCH_REHEARSE=1: rehearsal of the N>1 path on a box with fewer GPUs than ranks -- ranks share the cards
-    # round robin and rendezvous over gloo (RCCL refuses two ranks on one device).  Numbers from it mean nothing.
-    rehearse = os.environ.get("WAH_BENCH_REHEARSE") == "1"
-    if rehearse:
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dev = None
+    if not cpu_only:
         if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    red_dev = "cpu" if rehearse else dev  # where the two small reductions live
-
-    wah = importlib.import_module("gpu-wah_amd")
-    wah.lib()
+            local_rank %= torch.cuda.device_count()
+        elif local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: no GPU {local_rank} on this node")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device(f"cuda:{local_rank}")
+    dist = init_ranks(rank, world) if world > 1 else None
     kind, param, desc = WORKLOADS[args.workload]
+    extra = {"rehearsal": f"WAH_BENCH_REHEARSE={rehearse}: numbers mean nothing"} if rehearse else {}
 
+    def finish():
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    # ---- independent columns: compress only, fixed total -----------------------------------------------------------
     if args.workload == "columns":
-        n = args.words or 33554400
-        n_columns = args.columns or 64 * world
-        mine = wah.columns.shard_columns(n_columns, rank, world)
-        specs = [wah.columns.column_spec(c, n, args.seed) for c in mine]
-        batched = n % wah.columns.SEGMENT_WORDS == 0 and not args.per_column_launches
-        if batched:
-            # the rank's columns as one [columns, n] matrix: ONE launch compresses them all (whole 992-word segments,
-            # so the result is the columns' streams back to back; the segment index gives the column boundaries)
-            matrix = wah.columns.make_column_matrix(wah, specs, dev)
-            comp = wah.DeviceCompressor(matrix.numel(), device=dev, indexed=True)
-
+        n = args.words or COLUMN_WORDS
+        n_columns = args.columns or COLUMNS_TOTAL
+        mine, batches = column_plan(n_columns, rank, world, 1 if args.per_column_launches else args.columns_per_launch)
+        c_words_rank = 0.0
+        if cpu_only:
             def step():
-                wah.columns.compress_column_matrix(comp, matrix, wait=False)
-
-            step()
-            comp.status()
-            c_words_rank = float(comp.count.item())
+                pass
         else:
-            cols = [wah.columns.make_column(wah, sp, dev) for sp in specs]
-            comp = wah.DeviceCompressor(n, device=dev)
+            wah = importlib.import_module("gpu-wah_amd")
+            wah.lib()
+            specs = [wah.columns.column_spec(c, n, args.seed) for c in mine]
+            batched = n % wah.columns.SEGMENT_WORDS == 0 and not args.per_column_launches
+            # all of the rank's columns stay resident: one [columns, n] matrix, generated once
+            matrix = wah.columns.make_column_matrix(wah, specs, dev) if specs else None
+            widest = max((len(b) for b in batches), default=1)
+            comp = wah.DeviceCompressor(widest * n if batched else n, device=dev, indexed=batched)
             sizes = []
 
             def step():
-                sizes[:] = wah.columns.compress_columns(comp, cols)
+                row = 0
+                sizes.clear()
+                for b in batches:
+                    rows = matrix[row:row + len(b)]
+                    if batched:
+                        # ONE launch per batch: whole 992-word segments, so the result is the columns' streams back to
+                        # back; the segment index gives the column boundaries
+                        comp.run(rows.view(-1), n_words=rows.numel())
+                    else:
+                        comp.run(rows[0])
+                    sizes.append(comp.count.clone())
+                    row += len(b)
 
             step()
             comp.status()
             c_words_rank = float(sum(int(s.item()) for s in sizes))
-        elapsed = timed_steps(step, args.steps, args.warmup, dist, dev, red_dev)
-        comp.status()
-        stats = torch.tensor([4.0 * n * len(specs), c_words_rank], dtype=torch.float64, device=red_dev)
+        elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
+        if not cpu_only:
+            comp.status()
+        stats = torch.tensor([4.0 * n * len(mine), c_words_rank], dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(stats)
         if rank == 0:
             in_bytes_job, c_words_job = float(stats[0].item()), float(stats[1].item())
             out = {
-                "metric": "compress GB/s (input bits), independent 128 MiB bitmap columns",
+                "metric": "compress GB/s (input bits), 1024 independent 128 MiB bitmap columns",
                 "value": round(args.steps * in_bytes_job / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
                 "config": {"workload": desc, "words_per_column": n, "columns": n_columns,
-                           "columns_per_gpu": len(specs), "seed": args.seed,
-                           "launches_per_step": 1 if batched else len(specs),
+                           "columns_per_gpu": len(mine), "seed": args.seed, "launches_per_step": len(batches),
+                           "columns_per_launch": max((len(b) for b in batches), default=0),
                            "parallelism": f"column-shard x{world}, no collective"},
-                "compression_ratio_C_over_N": round(c_words_job * 4.0 / in_bytes_job, 6),
+                "compression_ratio_C_over_N": round(c_words_job * 4.0 / in_bytes_job, 6) if in_bytes_job else None,
             }
+            out.update(extra)
             print(json.dumps(out), flush=True)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        finish()
         return
 
     # ---- single bitmap per GPU: compress + decompress round trip ---------------------------------------------
     n = args.words or 268435200
+    if cpu_only:
+        elapsed = timed_steps(lambda: None, args.steps, args.warmup, dist, None)
+        if rank == 0:
+            out = {"metric": "compress+decompress GB/s (input bits), 1 GiB bitmap", "value": None, "unit": "GB/s",
+                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                   "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                   "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                   "config": {"workload": desc, "words": n, "seed": args.seed, "bitmaps_per_gpu": 1,
+                              "parallelism": f"column-shard x{world}, no collective"}}
+            out.update(extra)
+            print(json.dumps(out), flush=True)
+        finish()
+        return
+
+    wah = importlib.import_module("gpu-wah_amd")
+    wah.lib()
     d_in = (wah.gen_uniform_device(n, args.seed + rank, param, device=dev) if kind == "uniform"
             else wah.gen_clustered_device(n, args.seed + rank, param, device=dev))  # every rank: its own bitmap
     comp = wah.DeviceCompressor(n, device=dev)
@@ -226,7 +332,7 @@ def main():
         ev[2].record()
         events.append(ev)
 
-    elapsed = timed_steps(step, args.steps, args.warmup, dist, dev, red_dev)
+    elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
     comp.status()
     dec.status()
     timed = events[args.warmup:]
@@ -234,6 +340,18 @@ def main():
     dec_ms = sorted(e[1].elapsed_time(e[2]) for e in timed)
     comp_avg = sum(comp_ms) / len(comp_ms)
     dec_avg = sum(dec_ms) / len(dec_ms)
+
+    # the compress kernel on its own: a compress-only loop (no expand kernel's write drain in front of it)
+    for _ in range(2):
+        comp.run(d_in)
+    ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ce[0].record()
+    for _ in range(10):
+        comp.run(d_in)
+    ce[1].record()
+    torch.cuda.synchronize()
+    comp_isolated = ce[0].elapsed_time(ce[1]) / 10
+    comp.status()
 
     # on-box copy ceiling: 16 B/lane copy of the same bitmap (read + write)
     scratch = torch.empty_like(d_in)
@@ -288,32 +406,51 @@ def main():
             "compress_ms": {"avg": round(comp_avg, 4), "min": round(comp_ms[0], 4), "median": round(comp_ms[len(comp_ms) // 2], 4)},
             "decompress_ms": {"avg": round(dec_avg, 4), "min": round(dec_ms[0], 4), "median": round(dec_ms[len(dec_ms) // 2], 4)},
             "copy_ceiling_GBps": round(copy_gbps, 1),
-            "roofline": {"kernel": "compress_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+            "roofline": {"kernel": "compress_tile_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": tr.get("compress_bytes_per_launch"), "traffic_source": tr.get("source"),
+                         "traffic": tr.get("compress_bytes_per_launch"), "traffic_measured_in_run": False,
+                         "traffic_source": tr.get("source"),
                          "algorithmic_bytes_per_launch": algo_c, "launch_ms": round(comp_avg, 4),
+                         "launch_ms_isolated": round(comp_isolated, 4),
+                         "frac_isolated": round(algo_c / (comp_isolated * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "frac_of_copy_ceiling": round(achieved / copy_gbps, 4)},
             "roofline_decompress": {"kernel": "decode_sums_kernel + decode_expand_kernel", "bound": "hbm",
                                     "achieved": round(achieved_d, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": round(achieved_d / HBM_PEAK_GBPS, 4),
-                                    "traffic": tr.get("decompress_bytes_per_launch"),
+                                    "traffic": tr.get("decompress_bytes_per_launch"), "traffic_measured_in_run": False,
                                     "algorithmic_bytes_per_launch": algo_d, "launch_ms": round(dec_avg, 4)},
             "roofline_decompress_indexed": {"kernel": "decode_segments_kernel", "bound": "hbm",
                                             "achieved": round(algo_d / (idx_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                                             "unit": "GB/s", "frac": round(algo_d / (idx_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                             "traffic": tr.get("decompress_indexed_bytes_per_launch"),
+                                            "traffic_measured_in_run": False,
                                             "algorithmic_bytes_per_launch": algo_d,
                                             "launch_ms": round(idx_ms, 4),
                                             "note": "side measurement with the segment index kept by the compressor; not part of value"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, param, args.cpu_sample_mib, args.seed)
+        out.update(extra)
         print(json.dumps(out), flush=True)
+    finish()
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None:
+        if args.gpus > 1 or args.dry_launch:
+            return launch_ranks(args, argv)
+    elif int(world_env) != args.gpus:
+        print(f"bench.py: started with WORLD_SIZE={world_env} but --gpus {args.gpus}: start it with matching values "
+              f"(python bench.py --gpus N starts its own ranks)", file=sys.stderr)
+        return 2
+    run_rank(args)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())
