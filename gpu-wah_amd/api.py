@@ -252,7 +252,8 @@ class DeviceDecompressor:
         self.c_words = int(c_words)
         self.capacity = int(out_capacity_words)
         self.ws_bytes = int(lib().wah_decompress_workspace_bytes(self.c_words, self.capacity))
-        self.workspace = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        # zeroed once (include/wah.h: wah_workspace_init_device); the sums kernel keeps it up from then on
+        self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=device)
         self.out = torch.empty(max(self.capacity, 1), dtype=torch.int32, device=device)
         self.info = torch.zeros(2, dtype=torch.int64, device=device)  # [decoded words, groups]
 
@@ -295,7 +296,7 @@ def build_index_device(d_comp):
     _as_words(torch, d_comp)
     c = int(d_comp.numel())
     ws_bytes = int(lib().wah_decompress_workspace_bytes(c, 0))
-    workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=d_comp.device)
+    workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=d_comp.device)
     info = torch.zeros(2, dtype=torch.int64, device=d_comp.device)
     # a stream of c words has at most c segments (every segment holds at least one word)
     offsets = torch.zeros(c + 1, dtype=torch.int64, device=d_comp.device)
@@ -340,7 +341,7 @@ def merge_fills_device(d_comp):
     _as_words(torch, d_comp)
     c = int(d_comp.numel())
     ws_bytes = int(lib().wah_merge_fills_workspace_bytes(c))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=d_comp.device)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=d_comp.device)
     out = torch.empty(max(c, 1), dtype=torch.int32, device=d_comp.device)
     count = torch.zeros(1, dtype=torch.int64, device=d_comp.device)
     sp = _stream_ptr(torch)
@@ -442,7 +443,7 @@ def validate_device(d_comp):
     _as_words(torch, d_comp)
     c = int(d_comp.numel())
     ws_bytes = int(lib().wah_decompress_workspace_bytes(c, 0))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=d_comp.device)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=d_comp.device)
     report = torch.zeros(8, dtype=torch.int64, device=d_comp.device)
     _check(lib().wah_validate_device(d_comp.data_ptr(), c, report.data_ptr(), ws.data_ptr(), ws_bytes, _stream_ptr(torch)),
            "wah_validate_device")

@@ -59,18 +59,20 @@ CompressLayout compress_layout(uint64_t n_words) {
 
 struct DecodeLayout {
     uint64_t n_tiles;
-    size_t ctrl_off, desc_off, big_off, base_off, flags_off, total, zero_bytes;
+    size_t ctrl_off, desc_off, base_off, flags_off, total, scan_bytes;
 };
 
+// [control block][scan area of the sums kernel: one block per 64 x 256 workgroup tiles (+ the one a full last superrow
+//  publishes into)][tile bases][one flag byte per tile]
 DecodeLayout decode_layout(uint64_t c_words) {
     DecodeLayout l;
     l.n_tiles = ceil_div(c_words, (uint64_t)wah::kScanTileWords);
+    const uint64_t wg_tiles = ceil_div(l.n_tiles, (uint64_t)wah::kSumTilesPerGroup);
+    const uint64_t blocks = wg_tiles / wah::kSumScanBlockTiles + 1;
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
-    // generation rows, as in compress_layout(): at most 4 * n_tiles + 8 granules
-    l.zero_bytes = round256(l.desc_off + (4 * l.n_tiles + 8) * sizeof(uint32_t));
-    l.big_off = l.zero_bytes;
-    l.base_off = round256(l.big_off + (l.n_tiles + 1) * sizeof(uint64_t));
+    l.scan_bytes = blocks * wah::kSumScanBlockWords * sizeof(uint32_t);
+    l.base_off = round256(l.desc_off + l.scan_bytes);
     l.flags_off = round256(l.base_off + (l.n_tiles + 4) * sizeof(uint64_t)); // (+ two words for wah_validate_device)
     l.total = round256(l.flags_off + l.n_tiles + 16);                       // one byte per tile: contains empty fills
     return l;
@@ -411,9 +413,11 @@ int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out,
 int wah_compress_status(void *d_workspace, void *stream) { return read_status(d_workspace, stream); }
 int wah_decompress_status(void *d_workspace, void *stream) { return read_status(d_workspace, stream); }
 
+// clear_first: the workspace is scratch of unknown content (the bitop paths): zero its control block and scan area in
+// front of the launch, which makes it a fresh workspace every time.
 static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                          uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream, bool do_scan,
-                         bool do_expand) {
+                         bool do_expand, bool clear_first = false) {
     g_err[0] = 0;
     if (!d_out_info || !d_workspace || (c_words && !d_comp) || (do_expand && out_capacity_words && !d_out)) {
         set_err("null pointer");
@@ -436,18 +440,11 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
     char *ws = static_cast<char *>(d_workspace);
     hipError_t e = hipSuccess;
     if (do_scan) {
-        const int resident = c_words ? wah::decode_sums_grid(reinterpret_cast<uint32_t *>(ws), s) : 1;
-        if (resident < 1) {
-            set_err("residency census failed", hipGetLastError());
-            return WAH_ERR_HIP;
+        if (clear_first) e = wah::launch_clear(ws, l.base_off, s);
+        if (e == hipSuccess && c_words == 0) {
+            e = wah::launch_clear(d_out_info, 2 * sizeof(uint64_t), s);
+            if (e == hipSuccess && !clear_first) e = wah::launch_clear(ws + wah::kCtlError * sizeof(uint32_t), sizeof(uint32_t), s);
         }
-        // the sums kernel works on workgroup tiles of kSumTilesPerGroup expand tiles
-        const uint64_t wg_tiles = ceil_div(l.n_tiles, (uint64_t)wah::kSumTilesPerGroup);
-        const uint64_t grid64 = (uint64_t)resident < wg_tiles ? (uint64_t)resident : (wg_tiles ? wg_tiles : 1);
-        const uint64_t generations = (wg_tiles + grid64 - 1) / grid64;
-        const size_t used = round256(l.desc_off + (generations * ((grid64 + 3) & ~3ull) + 8) * sizeof(uint32_t));
-        e = wah::launch_clear(ws, used < l.zero_bytes ? used : l.zero_bytes, s);
-        if (e == hipSuccess && c_words == 0) e = wah::launch_clear(d_out_info, 2 * sizeof(uint64_t), s);
         if (e != hipSuccess) {
             set_err("clearing the workspace", e);
             return WAH_ERR_HIP;
@@ -461,11 +458,10 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
             a.tile_base = reinterpret_cast<uint64_t *>(ws + l.base_off);
             a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
             a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
-            a.big = reinterpret_cast<uint64_t *>(ws + l.big_off);
+            a.scan_words = l.scan_bytes / sizeof(uint32_t);
             a.tile_flags = reinterpret_cast<uint8_t *>(ws + l.flags_off);
             a.aligned16 = aligned16(d_comp) ? 1 : 0;
-            a.census = 0;
-            e = wah::launch_decode_sums(a, (int)grid64, s);
+            e = wah::launch_decode_sums(a, s);
             if (e != hipSuccess) {
                 set_err("decode sums kernel launch", e);
                 return WAH_ERR_HIP;
@@ -671,8 +667,9 @@ int wah_bitop_device(int op, uint64_t n_words, const uint32_t *d_a, uint64_t a_w
     char *sc = static_cast<char *>(d_scratch);
     uint32_t *bm_a = reinterpret_cast<uint32_t *>(sc + l.bitmap_a), *bm_b = reinterpret_cast<uint32_t *>(sc + l.bitmap_b);
     uint64_t *info_a = reinterpret_cast<uint64_t *>(sc + l.info_a), *info_b = reinterpret_cast<uint64_t *>(sc + l.info_b);
-    int rc = wah_decompress_device(d_a, a_words, bm_a, l.decoded_capacity, info_a, sc + l.ws_a, l.ws_a_bytes, stream);
-    if (rc == WAH_OK) rc = wah_decompress_device(d_b, b_words, bm_b, l.decoded_capacity, info_b, sc + l.ws_b, l.ws_b_bytes, stream);
+    // (the decode workspaces inside the caller's scratch are cleared in front of every use: scratch needs no initialisation)
+    int rc = decode_common(d_a, a_words, bm_a, l.decoded_capacity, info_a, sc + l.ws_a, l.ws_a_bytes, stream, true, true, true);
+    if (rc == WAH_OK) rc = decode_common(d_b, b_words, bm_b, l.decoded_capacity, info_b, sc + l.ws_b, l.ws_b_bytes, stream, true, true, true);
     if (rc != WAH_OK) return rc;
     wah::PairCheck check;
     check.info_a = info_a;
@@ -991,7 +988,10 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     const size_t ws0 = wah_decompress_workspace_bytes(c_words, 0);
     if (!hc.alloc(1, &d_comp, c_words * sizeof(uint32_t), "space for the compressed data")) return nullptr;
     if (!hc.alloc(3, &d_info, 2 * sizeof(uint64_t), "output size")) return nullptr;
-    if (!hc.alloc(4, &d_ws0, ws0, "scan workspace")) return nullptr;
+    bool fresh_ws = false;
+    if (!hc.alloc(4, &d_ws0, ws0, "scan workspace", &fresh_ws)) return nullptr;
+    // zeroed once; from then on the sums kernel keeps it up itself (launch epochs)
+    if (fresh_ws && wah_workspace_init_device(d_ws0, ws0, nullptr) != WAH_OK) return nullptr;
     if (c_words && !hip_ok(hipMemcpy(d_comp, comp_host, c_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
         return nullptr;
     t_in = hc.stop();

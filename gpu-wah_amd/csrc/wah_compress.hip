@@ -205,7 +205,7 @@ __device__ __forceinline__ void classify_pass2(const SegGroups &g, SegEnds e, u3
 // ===========================================================================
 // compress_tile_kernel
 //
-// Workgroup = one TILE of kTileWaves consecutive segments, one short-lived wavefront per segment, tile = blockIdx.x.
+// Workgroup = one TILE of kTileWaves x kWaveSegs consecutive segments, short-lived; tile = arrival order (draw_tile).
 //   every wave : 4 x 16-byte loads of its segment -> private 4 KiB LDS stage -> classify + compact in place
 //                (classify_compact) -> count to LDS -> barrier -> [wave 0: row scan] -> barrier -> final words
 //                (fill length = distance between consecutive run ends) straight from LDS to their place in the
@@ -225,10 +225,9 @@ __device__ __forceinline__ void classify_pass2(const SegGroups &g, SegEnds e, u3
 //   granule[r][0 .. i)  +  granule[r-1][0 .. 256)  +  slot[s][1 ..] of rows s0 .. r-2  +  slot[s][0]
 // The last tile of a row publishes the row's slot as soon as its own row is complete (no dependency on anything
 // older), the last tile of a superrow publishes the next superrow's slot[.][0].  So every dependency is "published
-// by a tile with a smaller blockIdx" and at most one hop old; rows r-2 and older had >= one whole row of time.
-// Order: workgroups are dispatched in blockIdx order (round robin over the XCDs, in order inside each), so the
-// lowest unfinished tile is always running or next in line on its XCD; every wait is bounded all the same
-// (WAH_ERR_TIMEOUT, never a hang).
+// by a tile with a smaller number" and at most one hop old; rows r-2 and older had >= one whole row of time.
+// Order: tile numbers are drawn in the order in which the workgroups start running (draw_tile, wah_device.hpp), so a
+// tile only ever waits for tiles that are running; every wait is bounded all the same (WAH_ERR_TIMEOUT, never a hang).
 // Epochs: the workspace is never cleared.  Every launch stamps what it publishes with the launch epoch kept in the
 // control block (read by every workgroup at its start, advanced by the LAST tile once its scan is complete -- by
 // then every other tile has published, hence started).  A zeroed workspace is epoch 0 = "nothing valid".  When
@@ -248,7 +247,6 @@ static_assert(kSlotShift - 32 == kCountBits, "the high half of a slot carries it
 static_assert(kScanBlockWords >= kSuperRows * kRowTiles + 2 * kRowSlots && kScanSlotsAt == kSuperRows * kRowTiles, "scan block layout");
 
 constexpr u32 kDirectLanes = 6; // up to this many lanes with missing entries are simply read again
-constexpr int kAuxSc1 = 16; // buffer load cache policy: sc1 = agent scope (served past the XCD-private caches)
 
 struct TileScan {
     u32x4 a, b; // granules of my row (entries below me; the descriptor cuts the rest off) and of the previous row
@@ -354,10 +352,11 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
     __shared__ u32 s_count[kTileWaves];
     __shared__ u32 s_prefix[kTileWaves];
     __shared__ u64 s_base;
+    __shared__ u32 s_tile;
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
-    const u32 tile = blockIdx.x;
+    const u32 tile = draw_tile(a.ctrl, &s_tile);
     const u32 seg0 = (tile * kTileWaves + wave) * kWaveSegs; // this wave's segments: seg0 .. seg0 + kWaveSegs - 1
 #ifdef WAH_DIAG
     u64 dg_t[6];
@@ -368,46 +367,13 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
 #define DG(i)
 #endif
 
-    // ---- launch epoch (same value for every workgroup of the launch: only the last tile's scan advances it) -------
-    const u32 stored_epoch = uniform32(a.ctrl[kCtlEpoch]);
-    const u32 magic = uniform32(a.ctrl[kCtlMagic]);
-    if (magic != 0u && magic != kWorkspaceMagic) { // neither a zeroed nor a used workspace
-        if (threadIdx.x == 0) atomicOr(a.ctrl + kCtlError, kErrWorkspace);
+    // ---- launch epoch (wah_device.hpp): the same value for every workgroup of the launch --------------------------------
+    const LaunchEpoch le = launch_epoch_begin(a.ctrl, tile, a.gen_desc, a.scan_words, a.keep_error);
+    if (le.bad) {
         if (tile == a.n_tiles - 1 && threadIdx.x == 0) *a.out_words = 0;
         return;
     }
-    const bool wrap = stored_epoch >= kEpochWrap;
-    const u32 epoch = (stored_epoch == 0u || wrap) ? 1u : stored_epoch;
-    if (wrap) {
-        // the epoch space is used up: stale granules could be taken for this launch's.  Tile 0 clears the scan
-        // area, everybody else waits for that (tile 0 has the smallest blockIdx: it is running).
-        const u32 wraps = uniform32(a.ctrl[kCtlWraps]);
-        if (tile == 0) {
-            for (u64 k = threadIdx.x; k < a.scan_words; k += blockDim.x)
-                __hip_atomic_store(a.gen_desc + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_store(a.ctrl + kCtlClearDone, wraps + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (threadIdx.x == 0) {
-                u32 spins = 0;
-                while (__hip_atomic_load(a.ctrl + kCtlClearDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wraps + 1u) {
-                    if (++spins > kMaxSpins) {
-                        atomicOr(a.ctrl + kCtlError, kErrTimeout);
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (tile == 0 && threadIdx.x == 0 && !a.keep_error) {
-        // a new launch: forget the previous one's status.  Completed before this tile publishes anything, and every
-        // error of this launch is raised by a tile that has seen something published.
-        __hip_atomic_store(a.ctrl + kCtlError, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    const u32 epoch = le.epoch;
 
     // ---- this wave's segments, one after the other through the wave's LDS buffer; the final words of each are parked
     //      in 16 registers per lane, so nothing of a tile that waits for its offset occupies LDS bandwidth or needs a
@@ -611,10 +577,7 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
                 *a.out_words = end;
                 if (a.seg_offsets) a.seg_offsets[a.n_segments] = end;
                 if (end > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
-                // every other tile has published its granule, so it has read the epoch: advance it for the next launch
-                if (wrap) __hip_atomic_store(a.ctrl + kCtlWraps, uniform32(a.ctrl[kCtlWraps]) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.ctrl + kCtlMagic, kWorkspaceMagic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.ctrl + kCtlEpoch, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                launch_epoch_end(a.ctrl, le); // every other tile has published, so it has read the epoch: advance it
             }
         }
     }

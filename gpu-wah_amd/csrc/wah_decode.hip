@@ -13,7 +13,7 @@ namespace {
 // decompress.cu:66-115).  Here:
 //   pass 1  decode_sums_kernel   : streaming reduce.  Tiles of 4096 compressed words; per tile the number of 31-bit
 //                                   groups it expands to, turned into exclusive tile bases by the same one-hop
-//                                   generation scan as compress.  Reads C once, writes 8 bytes per tile.
+//                                   row scan as compress.  Reads C once, writes 8 bytes per tile.
 //   pass 2  decode_expand_kernel : one workgroup per tile, tile words resident in LDS.  A tile OWNS the output
 //                                   segments (1024 groups -> 992 words) whose first group falls into it; each of its
 //                                   wavefronts expands whole segments: group -> source word by RANK (mbcnt over a
@@ -21,223 +21,230 @@ namespace {
 //                                   registers with two DPP shifts, dense 248-byte stores.
 // Any stream the reference decoder accepts is handled (arbitrary 30-bit counts, fills across segment boundaries).
 // ===========================================================================
-constexpr u32 kGenEscape = 0x7FFFFFFFu; // granule value: "total does not fit 31 bits, read the 64-bit side entry"
+// ---- decode_sums_kernel ---------------------------------------------------------------------------------------------
+// Short-lived workgroups, one per WORKGROUP TILE of kSumWaves expand tiles (8 x 4096 words = 128 KiB of the stream),
+// workgroup tile = arrival order.  A wave sums the group counts (getCounts, kernels.cu:291-309) of one expand tile: all
+// sixteen 16-byte loads of a lane are issued before the first is used.  The workgroup tile's total is published as ONE
+// 8-byte granule {epoch:16, groups:48}; wave 0 then resolves the groups in front of the tile with the same one-hop ROW
+// SCAN as the compress kernel (wah_compress.hip), here over 8-byte granules:
+//   granule[r][0 .. i)  +  granule[r-1][0 .. 256)  +  slot[s][1 ..] of rows s0 .. r-2  +  slot[s][0]
+// (rows of 256 workgroup tiles, superrows of 64 rows; a row's last tile publishes the row's slot, a superrow's last tile
+// the next superrow's slot[0]) and writes the exclusive bases of its eight expand tiles.  Nothing is persistent: no
+// residency census, no arrival tickets; launch epochs (wah_device.hpp) instead of clearing; every wait is bounded.
+// Totals saturate at 2^47 groups (a stream that claims more -- 500 TB of bitmap -- is reported as WAH_ERR_STREAM).
+constexpr u32 kSumWaves = (u32)kSumTilesPerGroup;
+constexpr u32 kSumRowTiles = 256;
+constexpr u32 kSumSuperRows = 64;
+constexpr u32 kSumSlotShift = 48;
+constexpr u64 kSumValueMask = (1ull << kSumSlotShift) - 1ull;
+constexpr u64 kSumSaturate = 1ull << 47;
+static_assert(kSumScanBlockWords >= 2 * kSumSuperRows * kSumRowTiles + 2 * (kSumSuperRows + 1) && kSumScanSlotsAt == 2 * kSumSuperRows * kSumRowTiles,
+              "scan block layout");
 
-// generation scan with 64-bit totals (a tile of fills can expand to more than 2^31 groups)
-__device__ __forceinline__ u64 resolve_generation64(const u32 *gdesc, const u64 *big, u32 gen, u32 slot, u32 G,
-                                                    u32 row_stride, u64 aggregate, GenScan &st, u64 &own_prev64,
-                                                    u64 &below_prev64, u32 lane, u32 *ctrl) {
-    const u32 *cur = gdesc + (u64)gen * row_stride;
-    const u32 *prv = cur - row_stride;
-    bool need_prev = gen > 0 && slot + 1 < G, need_cur = slot > 0;
-    u64 above = 0, below = 0;
-    u32 spins = 0;
-    while (need_prev || need_cur) {
-        u64 sum_cur = 0, sum_prev = 0;
-        bool bad_cur = false, bad_prev = false;
-        for (u32 k = lane; k < G; k += 64u) {
-            if (need_cur && k < slot) {
-                const u32 e = __hip_atomic_load(cur + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bad_cur |= !(e & kGenValid);
-                u64 v = e & ~kGenValid;
-                if (v == kGenEscape && (e & kGenValid))
-                    v = __hip_atomic_load(big + ((u64)gen * G + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sum_cur += v;
-            }
-            if (need_prev && k > slot) {
-                const u32 e = __hip_atomic_load(prv + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bad_prev |= !(e & kGenValid);
-                u64 v = e & ~kGenValid;
-                if (v == kGenEscape && (e & kGenValid))
-                    v = __hip_atomic_load(big + ((u64)(gen - 1) * G + k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sum_prev += v;
-            }
-        }
-        bool progressed = false;
-        if (need_cur && !__any(bad_cur)) {
-            below = uniform64(wave_sum(sum_cur));
-            need_cur = false;
-            progressed = true;
-        }
-        if (need_prev && !__any(bad_prev)) {
-            above = uniform64(wave_sum(sum_prev));
-            need_prev = false;
-            progressed = true;
-        }
-        if (!progressed) {
-            if (++spins > kMaxSpins) {
-                if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    if (gen > 0) st.gen_base += below_prev64 + own_prev64 + above;
-    below_prev64 = below;
-    own_prev64 = aggregate;
-    return st.gen_base + below;
+__device__ __forceinline__ u64 sat_add(u64 x, u64 y) {
+    const u64 s = x + y;
+    return s < kSumSaturate ? s : kSumSaturate;
 }
 
-// Workgroup = kSumWorkers worker wavefronts + 1 scan wave.  A worker sums one whole expand tile (4096 words) per
-// iteration in four rolling 4 KiB rounds; the workgroup's tile (kSumWorkers expand tiles, 128 KiB) costs ONE
-// granule, so the scan traffic stays below 1 % of the stream.
-constexpr int kSumWorkers = kSumTilesPerGroup;
+struct SumScan {
+    u32x4 a[2], b[2]; // 8-byte granules of my row (entries below me) and of the previous row: four per lane
+    u64 c;            // slot of my superrow: lane 0 = groups in front of it, lane 1 + k = groups of its row k
+};
 
-__global__ __launch_bounds__((kSumWorkers + 1) * 64) void decode_sums_kernel(const ScanArgs a) {
-    __shared__ u64 s_part[4][kSumWorkers];
-    __shared__ u32 s_arrived[4];
-    __shared__ u64 s_total[4];
-    __shared__ u32 s_total_flag[4];
-    __shared__ u32 s_scanned; // tiles the scan wave has consumed (flow control of the 4-deep hand-off ring)
-    __shared__ u32 s_arrival;
+__device__ __forceinline__ void sum_scan_issue(u32 *block, u32 row_in_super, u32 idx, u32 n_slots, u32 lane, bool need_a, bool need_b,
+                                               bool need_c, SumScan &p) {
+    if (need_a) {
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(block + (u64)row_in_super * kSumRowTiles * 2u, idx * 8u);
+        p.a[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 32u, 0, kAuxSc1);
+        p.a[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 32u + 16u, 0, kAuxSc1);
+    }
+    if (need_b) {
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(block + (u64)(row_in_super - 1u) * kSumRowTiles * 2u, kSumRowTiles * 8u);
+        p.b[0] = __builtin_amdgcn_raw_buffer_load_b128(rb, lane * 32u, 0, kAuxSc1);
+        p.b[1] = __builtin_amdgcn_raw_buffer_load_b128(rb, lane * 32u + 16u, 0, kAuxSc1);
+    }
+    if (need_c) {
+        const __amdgpu_buffer_rsrc_t rc = make_rsrc(block + kSumScanSlotsAt, n_slots * 8u);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rc, lane * 8u, 0, kAuxSc1);
+        p.c = ((u64)v.y << 32) | v.x;
+    }
+}
+
+__global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanArgs a) {
+    __shared__ u64 s_part[kSumWaves];
+    __shared__ u32 s_empty[kSumWaves];
+    __shared__ u32 s_tile;
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
-    const bool worker = wave < (u32)kSumWorkers;
+    const u32 wt = draw_tile(a.ctrl, &s_tile);     // workgroup tile: arrival order (wah_device.hpp)
+    const u32 n_tiles = (u32)a.n_tiles;            // expand tiles (4096 words)
+    const u32 n_wg_tiles = gridDim.x;
+    const u32 et = wt * kSumWaves + wave;          // this wave's expand tile
 
-    if (threadIdx.x < 4) {
-        s_arrived[threadIdx.x] = 0;
-        s_total_flag[threadIdx.x] = 0;
+    const LaunchEpoch le = launch_epoch_begin(a.ctrl, wt, a.gen_desc, a.scan_words, 0);
+    if (le.bad) {
+        if (wt == n_wg_tiles - 1 && threadIdx.x == 0) a.info[0] = a.info[1] = 0;
+        return;
     }
-    if (threadIdx.x == 0) {
-        s_scanned = 0;
-        s_arrival = draw_arrival(a.ctrl);
+    const u32 epoch = le.epoch;
+
+    // ---- this wave's expand tile: sum of the group counts ----------------------------------------------------------
+    // A fill word of count 0 expands to nothing; the reference decoder steps over it (kernels.cu:332-354).  The expand
+    // kernel's rank arithmetic assumes that every word owns at least one group, so every tile is checked here and
+    // expand takes its index-map route for the tiles concerned (tile_flags).
+    u64 mine = 0;
+    bool has_empty = false;
+    if (et < n_tiles) {
+        const u64 w0 = (u64)et * kScanTileWords;
+        if (a.aligned16 && w0 + kScanTileWords <= a.c_words) {
+            const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.comp + w0, kScanTileWords * 4u);
+            u32x4 v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + 1024u * k, 0, 0);
+            u32 lo = 1;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { // four counts of < 2^30 each fit 32 bits
+                const u32 nx = word_groups(v[k].x), ny = word_groups(v[k].y), nz = word_groups(v[k].z), nw = word_groups(v[k].w);
+                mine += (u64)(nx + ny + nz + nw);
+                lo = min(min(lo, min(nx, ny)), min(nz, nw));
+            }
+            has_empty = lo == 0u;
+        } else { // the stream's last tile, or a stream that is only 4-byte aligned: word by word, bounds checked
+            for (u32 i = lane; i < (u32)kScanTileWords; i += 64u) {
+                if (w0 + i < a.c_words) {
+                    const u32 n = word_groups(a.comp[w0 + i]);
+                    mine += n;
+                    has_empty |= n == 0u;
+                }
+            }
+        }
+    }
+    const u64 wave_total = uniform64(wave_sum(mine));
+    const bool any_empty = __any(has_empty);
+    if (lane == 0) {
+        s_part[wave] = wave_total;
+        s_empty[wave] = any_empty ? 1u : 0u;
+        if (et < n_tiles) a.tile_flags[et] = any_empty ? 1 : 0;
     }
     __syncthreads();
-    const u32 arrival = uniform32(s_arrival);
-    if (a.census) {
-        if (threadIdx.x == 0) { // residency census, see compress_kernel
-            const u64 t0 = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t0 < 3000) __builtin_amdgcn_s_sleep(8);
-            if (arrival == 0)
-                a.ctrl[kCtlCensus] = __hip_atomic_load(a.ctrl + kCtlStart, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        return;
-    }
-    const u32 stride = gridDim.x;
-    const u32 row_stride = (stride + 3u) & ~3u;
-    const u32 n_tiles = (u32)a.n_tiles;                                      // expand tiles (4096 words)
-    const u32 n_wg_tiles = (n_tiles + (u32)kSumWorkers - 1u) / (u32)kSumWorkers; // workgroup tiles
+    if (wave != 0) return;
 
-    if (!worker) {
-        // scan wave: workgroup-tile totals -> exclusive bases; then the bases of the expand tiles inside
-        GenScan scan = {0, 0, 0};
-        u64 own_prev = 0, below_prev = 0;
-        u32 gen = 0;
-        for (u32 wt = arrival; wt < n_wg_tiles; wt += stride, ++gen) {
-            const u32 q = gen & 3u;
-            if (!lds_wait(&s_total_flag[q], gen + 1u, a.ctrl, lane)) break;
-            const u64 total = uniform64(lds_ld64(&s_total[q]));
-            const u64 part = lane < (u32)kSumWorkers ? lds_ld64(&s_part[q][lane]) : 0ull;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) lds_st(&s_scanned, gen + 1u); // the ring slot may be reused
-            const u64 excl = resolve_generation64(a.gen_desc, a.big, gen, arrival, stride, row_stride, total, scan, own_prev,
-                                                  below_prev, lane, a.ctrl);
-            // lane w: groups in front of expand tile wt * kSumWorkers + w
-            const u64 incl_part = wave_scan_incl(part, lane);
-            const u32 et = wt * (u32)kSumWorkers + lane;
-            if (lane < (u32)kSumWorkers && et < n_tiles) a.tile_base[et] = excl + (incl_part - part);
-            if (lane == 0 && wt == n_wg_tiles - 1) {
-                const u64 groups = excl + total;
-                a.tile_base[n_tiles] = groups;
-                a.info[1] = groups;
-                a.info[0] = (31ull * groups + 31ull) / 32ull; // decompress.cu:84-93
+    // ---- wave 0: the workgroup tile's total goes out, then the groups in front of it ---------------------------------
+    const u64 part = lane < kSumWaves ? s_part[lane] : 0ull;
+    const u64 incl_part = wave_scan_incl(part, lane);
+    u64 total = uniform64(__shfl(incl_part, 63));
+    bool overflow = total >= kSumSaturate;
+    if (overflow) total = kSumSaturate;
+    const u32 row = wt / kSumRowTiles, idx = wt % kSumRowTiles, sup = row / kSumSuperRows, row0 = sup * kSumSuperRows;
+    const bool has_prev = row > row0;
+    const u32 n_slots = has_prev ? row - row0 : 1u;
+    u32 *const block = a.gen_desc + (u64)sup * kSumScanBlockWords;
+    u64 *const my_row = reinterpret_cast<u64 *>(block) + (u64)(row - row0) * kSumRowTiles;
+    u64 *const slots = reinterpret_cast<u64 *>(block + kSumScanSlotsAt);
+    if (lane == 0) __hip_atomic_store(my_row + idx, ((u64)epoch << kSumSlotShift) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    SumScan poll = {};
+    bool need_a = true, need_b = has_prev, need_c = true;
+    sum_scan_issue(block, row - row0, idx, n_slots, lane, need_a, need_b, need_c, poll);
+    u64 sum_a = 0, sum_b = 0, sum_c = 0;
+    u32 spins = 0;
+    auto granule = [](const u32x4 &q, int h) { return ((u64)(h ? q.w : q.y) << 32) | (h ? q.z : q.x); };
+    for (;;) {
+        u32 bad_a = 0, bad_b = 0;
+        bool bad_c = false;
+        u64 ba = 0, bb = 0, bc = 0;
+        if (need_a) {
+            u64 sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u64 gk = granule(poll.a[k >> 1], k & 1);
+                if (4u * lane + k < idx && (u32)(gk >> kSumSlotShift) != epoch) bad_a |= 1u << k;
+                sum += gk & kSumValueMask; // entries at and above my index lie behind the descriptor and read as zero
+            }
+            ba = __ballot(bad_a != 0u);
+            if (ba == 0) {
+                sum_a = uniform64(wave_sum(sum));
+                need_a = false;
+                if (idx == kSumRowTiles - 1u && lane == 0) // my row is complete with me: publish its total
+                    __hip_atomic_store(slots + 1u + (row - row0), ((u64)epoch << kSumSlotShift) | sat_add(sum_a, total), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        return;
-    }
-
-    // worker waves: stream one expand tile per iteration, sum the group counts (getCounts, kernels.cu:291-309)
-    uint4 pre[4];
-    // A fill word of count 0 expands to nothing; the reference decoder steps over it (kernels.cu:332-354).  The
-    // expand kernel's rank arithmetic assumes that every word owns at least one group, so every tile is checked here
-    // and expand takes its index-map route for the tiles concerned (tile_flags).  `pre_whole`: the prefetched round
-    // consists of real words only (no padding past the end, which is written as empty fills); `pre_empty`: a round
-    // that needed bounds checks contains an empty fill among its real words.
-    bool pre_empty = false, pre_whole = true;
-    // round `rd` (0..3) of expand tile `et`: 1024 words as four fully coalesced 1 KiB loads (order is irrelevant)
-    auto load_round = [&](u32 et, u32 rd) {
-        const u64 w0 = (u64)et * kScanTileWords + (u64)rd * 1024u;
-        if (a.aligned16 && w0 + 1024u <= a.c_words) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(a.comp + w0);
+        if (need_b) {
+            u64 sum = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pre[k] = src[k * 64 + (int)lane];
-            pre_whole = true;
-            pre_empty = false;
+            for (int k = 0; k < 4; ++k) {
+                const u64 gk = granule(poll.b[k >> 1], k & 1);
+                if ((u32)(gk >> kSumSlotShift) != epoch) bad_b |= 1u << k;
+                sum += gk & kSumValueMask;
+            }
+            bb = __ballot(bad_b != 0u);
+            if (bb == 0) {
+                sum_b = uniform64(wave_sum(sum));
+                need_b = false;
+            }
+        }
+        if (need_c) {
+            // slot 0 of superrow 0 is never written: nothing lies in front of the first tile
+            const bool wanted = lane < n_slots && !(sup == 0u && lane == 0u);
+            bad_c = wanted && (u32)(poll.c >> kSumSlotShift) != epoch;
+            bc = __ballot(bad_c);
+            if (bc == 0) {
+                sum_c = uniform64(wave_sum(wanted ? poll.c & kSumValueMask : 0ull));
+                need_c = false;
+            }
+        }
+        if (!(need_a || need_b || need_c)) break;
+        if (++spins > kMaxSpins) {
+            if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
+            break;
+        }
+        // wait for the missing entry with the highest tile number (published last), then read the missing lanes again
+        const u64 *target;
+        if (need_a) {
+            const u32 hl = 63u - (u32)__builtin_clzll(ba);
+            const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_a, (int)hl);
+            target = my_row + 4u * hl + (31u - (u32)__builtin_clz(km));
+        } else if (need_b) {
+            const u32 hl = 63u - (u32)__builtin_clzll(bb);
+            const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_b, (int)hl);
+            target = my_row - kSumRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
         } else {
-            u32 t[16];
-            pre_whole = false;
-            pre_empty = false;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const u64 i = w0 + (u64)(k / 4) * 256u + (u64)lane * 4u + (u64)(k % 4);
-                t[k] = i < a.c_words ? a.comp[i] : 0x80000000u; // past the end: a fill of zero groups
-                pre_empty |= i < a.c_words && word_groups(t[k]) == 0u;
+            target = slots + (63u - (u32)__builtin_clzll(bc));
+        }
+        bool timed_out = false;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((u32)(__hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> kSumSlotShift) == epoch) break;
+            if (++spins > kMaxSpins) {
+                timed_out = true;
+                break;
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pre[k] = make_uint4(t[4 * k], t[4 * k + 1], t[4 * k + 2], t[4 * k + 3]);
         }
-    };
-    if (arrival < n_wg_tiles) load_round(arrival * (u32)kSumWorkers + wave, 0);
-    u32 gen = 0;
-    for (u32 wt = arrival; wt < n_wg_tiles; wt += stride, ++gen) {
-        const u32 et = wt * (u32)kSumWorkers + wave;
-        u64 mine = 0;
-        bool tile_empty = false;
-#pragma unroll
-        for (u32 rd = 0; rd < 4; ++rd) {
-            uint4 cur[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cur[k] = pre[k];
-            const bool cur_whole = pre_whole;
-            tile_empty |= pre_empty;
-            // rolling prefetch: next round of this tile, or round 0 of this wave's next tile
-            if (rd < 3)
-                load_round(et, rd + 1);
-            else if (wt + stride < n_wg_tiles)
-                load_round((wt + stride) * (u32)kSumWorkers + wave, 0);
-            u32 round_min = 1;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { // four counts of < 2^30 each fit 32 bits; words past the end are empty fills
-                const u32 nx = word_groups(cur[k].x), ny = word_groups(cur[k].y), nz = word_groups(cur[k].z), nw = word_groups(cur[k].w);
-                mine += (u64)(nx + ny + nz + nw);
-                round_min = min(min(round_min, min(nx, ny)), min(nz, nw));
-            }
-            if (cur_whole) tile_empty |= round_min == 0u;
+        if (timed_out) {
+            if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
+            break;
         }
-        {
-            const bool any_empty = __any(tile_empty);
-            if (lane == 0 && (u64)et < a.n_tiles) a.tile_flags[et] = any_empty ? 1 : 0;
-        }
-        const u64 wave_total = uniform64(wave_sum(mine));
-        const u32 q = gen & 3u;
-        u32 last = 0;
-        if (lane == 0) {
-            // the ring slot is free once the scan wave has consumed the tile that used it 4 generations ago
-            if (gen >= 4) lds_wait_reached(&s_scanned, gen - 3u, a.ctrl);
-            __hip_atomic_store((lds_u64_ptr)&s_part[q][wave], wave_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            last = __hip_atomic_fetch_add((lds_u32_ptr)&s_arrived[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ==
-                   (u32)kSumWorkers - 1u;
-        }
-        if (uniform32(last)) {
-            if (lane == 0) {
-                u64 total = 0;
-#pragma unroll
-                for (int w = 0; w < kSumWorkers; ++w) total += lds_ld64(&s_part[q][w]);
-                // publish: one 4-byte granule; totals of 2^31 - 1 groups or more go through the 64-bit side entry
-                if (total >= kGenEscape) {
-                    __hip_atomic_store(a.big + ((u64)gen * stride + arrival), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    publish_generation(a.gen_desc, gen, arrival, row_stride, kGenEscape);
-                } else {
-                    publish_generation(a.gen_desc, gen, arrival, row_stride, (u32)total);
-                }
-                lds_st(&s_arrived[q], 0u);
-                __hip_atomic_store((lds_u64_ptr)&s_total[q], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                lds_publish(&s_total_flag[q], gen + 1u);
-            }
+        if (need_a && bad_a != 0u) sum_scan_issue(block, row - row0, idx, n_slots, lane, true, false, false, poll);
+        if (need_b && bad_b != 0u) sum_scan_issue(block, row - row0, idx, n_slots, lane, false, true, false, poll);
+        if (need_c && bad_c) sum_scan_issue(block, row - row0, idx, n_slots, lane, false, false, true, poll);
+    }
+    const u64 base = sat_add(sat_add(sum_c, sum_b), sum_a);
+    const u64 end = sat_add(base, total);
+    overflow |= end >= kSumSaturate;
+    // lane w: groups in front of expand tile wt * kSumWaves + w
+    if (lane < kSumWaves && et + lane < n_tiles) a.tile_base[et + lane] = base + (incl_part - part);
+    if (lane == 0) {
+        if (overflow) atomicOr(a.ctrl + kCtlError, kErrStream);
+        if (idx == kSumRowTiles - 1u && row - row0 == kSumSuperRows - 1u) // last tile of a superrow
+            __hip_atomic_store(reinterpret_cast<u64 *>(a.gen_desc + (u64)(sup + 1u) * kSumScanBlockWords + kSumScanSlotsAt),
+                               ((u64)epoch << kSumSlotShift) | end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wt == n_wg_tiles - 1) {
+            a.tile_base[n_tiles] = end;
+            a.info[1] = end;
+            a.info[0] = (31ull * end + 31ull) / 32ull; // decompress.cu:84-93
+            launch_epoch_end(a.ctrl, le);
         }
     }
 }
@@ -862,34 +869,9 @@ __global__ __launch_bounds__(kSegDecodeWaves * 64, 6) void bitop_many_segments_k
 
 } // namespace
 
-int decode_sums_grid(u32 *d_ctrl, hipStream_t s) {
-    static int cached[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (cached[dev] > 0) return cached[dev];
-    const int upper = persistent_grid(reinterpret_cast<const void *>(&decode_sums_kernel), (kSumWorkers + 1) * 64, ~0ull);
-    ScanArgs a = {};
-    a.ctrl = d_ctrl;
-    a.census = 1;
-    int resident = 0;
-    if (launch_clear(d_ctrl, kCtlWords * sizeof(u32), s) == hipSuccess) {
-        hipLaunchKernelGGL(decode_sums_kernel, dim3(upper), dim3((kSumWorkers + 1) * 64), 0, s, a);
-        u32 seen = 0;
-        if (hipGetLastError() == hipSuccess &&
-            hipMemcpyAsync(&seen, d_ctrl + kCtlCensus, sizeof seen, hipMemcpyDeviceToHost, s) == hipSuccess &&
-            hipStreamSynchronize(s) == hipSuccess)
-            resident = (int)seen;
-    }
-    if (resident < 1) return -1;
-    if (resident > upper) resident = upper;
-    resident = whole_per_cu(resident);
-    cached[dev] = resident;
-    return resident;
-}
-
-hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(decode_sums_kernel, dim3(grid), dim3((kSumWorkers + 1) * 64), 0, s, a);
+hipError_t launch_decode_sums(const ScanArgs &a, hipStream_t s) {
+    const u64 wg_tiles = (a.n_tiles + kSumWaves - 1) / kSumWaves;
+    hipLaunchKernelGGL(decode_sums_kernel, dim3((unsigned)wg_tiles), dim3(kSumWaves * 64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -36,7 +36,7 @@ using u64 = uint64_t;
 #define WAH_STAMP_FLUSH(ctrl)
 #endif
 
-constexpr u32 kMaxSpins = 1u << 21; // bounded look-back wait
+constexpr u32 kMaxSpins = 1u << 21; // bound of every in-kernel wait (polls with a sleep in between: seconds)
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 // wave-uniform by construction; readfirstlane tells the compiler so (keeps masks and offsets in SGPRs)
@@ -95,102 +95,6 @@ __device__ __forceinline__ u64 uniform64(u64 v) {
 }
 
 
-// Arrival ticket: the order in which workgroups actually start running.  Tiles are dealt round robin in THIS
-// order (never in blockIdx order, which says nothing about dispatch), so a workgroup only ever waits for
-// workgroups that are already running.
-__device__ __forceinline__ u32 draw_arrival(u32 *ctrl) {
-    return __hip_atomic_fetch_add(ctrl + kCtlStart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ---------------------------------------------------------------------------
-// Generation scan: the one-hop offset resolution of the persistent compress kernel.
-//
-// With the static round robin (tile = slot + generation * G) the G tiles of a generation are in flight together,
-// so a chained look-back needs several store->poll hops per generation and every workgroup stalls for all of them.
-// Here each tile publishes ONE 4-byte granule {valid, words} in its generation's row, and reads
-//     row[gen][0 .. slot)     -> words in front of it inside its generation            (poll until all valid)
-//     row[gen-1](slot .. G)   -> the rest of the previous generation's total          (normally valid already)
-// Every workgroup carries the running total of all earlier generations in registers (GenScan), so there is no
-// prefix descriptor, no chain and exactly one hop: publish, poll once, done.  Granules are naturally aligned
-// 4-byte words written and read with agent-scope relaxed atomics (sc1), the data is the flag.
-// ---------------------------------------------------------------------------
-constexpr u32 kGenValid = 0x80000000u;
-
-struct GenScan {
-    u64 gen_base;   // words of all generations before the current one
-    u32 below_prev; // previous generation: words of slots below mine
-    u32 own_prev;   // previous generation: my own words
-};
-
-__device__ __forceinline__ void publish_generation(u32 *gdesc, u32 gen, u32 slot, u32 row_stride, u32 aggregate) {
-    __hip_atomic_store(gdesc + (u64)gen * row_stride + slot, kGenValid | aggregate, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Whole wavefront.  Returns the number of words in front of tile (gen, slot); `aggregate` is that tile's own count
-// (already published).
-__device__ __forceinline__ u64 resolve_generation(const u32 *gdesc, u32 gen, u32 slot, u32 G, u32 row_stride,
-                                                  u32 aggregate, GenScan &st, u32 lane, u32 *ctrl) {
-    const u32 *cur = gdesc + (u64)gen * row_stride;
-    const u32 *prv = cur - row_stride; // only dereferenced when gen > 0
-
-    bool need_prev = gen > 0 && slot + 1 < G, need_cur = slot > 0;
-    u32 above = 0, below = 0, spins = 0;
-    while (need_prev || need_cur) {
-        u32 sum_cur = 0, sum_prev = 0;
-        bool bad_cur = false, bad_prev = false;
-        // lane l looks at entries 2l, 2l+1 (+128 per trip) as one 8-byte load per row
-        for (u32 k0 = 2u * lane; k0 < G; k0 += 128u) {
-            if (need_cur && k0 < slot) {
-                const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(cur + k0), __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
-                const u32 e0 = (u32)v, e1 = (u32)(v >> 32);
-                bad_cur |= !(e0 & kGenValid);
-                sum_cur += e0 & ~kGenValid;
-                if (k0 + 1 < slot) {
-                    bad_cur |= !(e1 & kGenValid);
-                    sum_cur += e1 & ~kGenValid;
-                }
-            }
-            if (need_prev && k0 + 1 > slot) {
-                const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(prv + k0), __ATOMIC_RELAXED,
-                                                __HIP_MEMORY_SCOPE_AGENT);
-                const u32 e0 = (u32)v, e1 = (u32)(v >> 32);
-                if (k0 > slot) {
-                    bad_prev |= !(e0 & kGenValid);
-                    sum_prev += e0 & ~kGenValid;
-                }
-                if (k0 + 1 < G) {
-                    bad_prev |= !(e1 & kGenValid);
-                    sum_prev += e1 & ~kGenValid;
-                }
-            }
-        }
-        bool progressed = false;
-        if (need_cur && !__any(bad_cur)) {
-            below = uniform32(wave_sum32(sum_cur));
-            need_cur = false;
-            progressed = true;
-        }
-        if (need_prev && !__any(bad_prev)) {
-            above = uniform32(wave_sum32(sum_prev));
-            need_prev = false;
-            progressed = true;
-        }
-        if (!progressed) {
-            if (++spins > kMaxSpins) {
-                if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    if (gen > 0) st.gen_base += (u64)st.below_prev + st.own_prev + above;
-    st.below_prev = below;
-    st.own_prev = aggregate;
-    return st.gen_base + below;
-}
-
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 
@@ -207,67 +111,82 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, u32 b
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x27000);
 }
 
-// Tile assignment is a static round robin over the workgroups in ARRIVAL order: the workgroup that draws arrival
-// ticket v processes tiles v, v + G, v + 2G, ... (G = grid size).  Every generation of G consecutive tiles is
-// then in flight at once and no workgroup ever holds a tile that sits below a tile somebody else is already
-// waiting behind (dynamic tickets drawn ahead of time do exactly that, and serialise the scan).  It needs all
-// G workgroups to be resident together: the host sizes G from a residency census of this very kernel
-// (census mode below), and every wait is bounded, so a lost workgroup ends in WAH_ERR_TIMEOUT, never in a hang.
-// Hand-offs inside the workgroup go through LDS words, not s_barrier: a wave only ever waits for the one thing it
-// needs.  LDS operations of a wave execute in order and the LDS is coherent inside the CU, so "write data, then
-// write flag" / "see flag, then read data" is enough; the waits below only drain the LDS counter (lgkmcnt),
-// never the vector-memory counter -- the prefetched loads stay in flight.
-// (explicit LDS address space + relaxed workgroup atomics: a volatile access through a generic pointer would be
-//  emitted as a FLAT instruction, which counts on the vector-memory counter as well and forces vmcnt(0) waits)
-__device__ __forceinline__ u32 lds_ld(const u32 *p) {
-    return __hip_atomic_load((lds_u32_ptr)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ u64 lds_ld64(const u64 *p) {
-    return __hip_atomic_load((lds_u64_ptr)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_st(u32 *p, u32 v) {
-    __hip_atomic_store((lds_u32_ptr)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_publish(u32 *flag, u32 value) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    lds_st(flag, value);
-}
-// A waiting wave must not compete with the working ones: the hardware favours the OLDEST wave of a SIMD, and the
-// oldest waves are exactly the ones that finish first and wait (measured: a busy spin made the youngest worker of a
-// SIMD take 1.75x as long as the oldest).  So: lowest priority and a short sleep between polls (128 cycles; longer ones only delay the hand-over).
-__device__ __forceinline__ bool lds_wait(const u32 *flag, u32 value, u32 *ctrl, u32 lane) {
-    if (lds_ld(flag) != value) {
-        __builtin_amdgcn_s_setprio(0);
-        for (u32 spins = 0; lds_ld(flag) != value;) {
-            if (++spins > kMaxSpins) {
-                if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
-                __builtin_amdgcn_s_setprio(1);
-                return false;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        __builtin_amdgcn_s_setprio(1);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    return true;
+// ---------------------------------------------------------------------------
+// Launch epochs: how the scan areas of the tile kernels (compress_tile_kernel, decode_sums_kernel) get by without
+// being cleared.  Everything a launch publishes is stamped with the launch epoch kept in the control block: read by
+// every workgroup at its start, advanced by the LAST tile once its scan is complete -- by then every other tile has
+// published, hence started.  A zeroed workspace is epoch 0 = "nothing valid".  When the epoch space is used up, the
+// next launch has tile 0 clear the scan area while the others wait for it (tile 0 has the smallest blockIdx: it is
+// running).  Called by ALL threads of the workgroup (it contains barriers in the wrap case).
+// ---------------------------------------------------------------------------
+struct LaunchEpoch {
+    u32 epoch;
+    bool wrap, bad;
+};
+
+// Tile number of a workgroup of a tile kernel = the order in which workgroups START RUNNING (one agent-scope atomic per
+// workgroup), never blockIdx: a tile only ever waits for tiles with smaller numbers, and those have been drawn, so they
+// are running (or done) -- whatever else shares the GPU.  With tile = blockIdx two such kernels running side by side
+// (two streams, two processes) can starve each other for good: the XCDs dispatch their shares of a grid independently,
+// so kernel A's waiting tiles can fill one XCD while its lowest tile needs a slot on another that kernel B's waiting
+// tiles fill, and vice versa (seen: multi-second stalls with two ranks on one card).  Called by ALL threads.
+__device__ __forceinline__ u32 draw_tile(u32 *ctrl, u32 *s_tile) {
+    if (threadIdx.x == 0) *s_tile = __hip_atomic_fetch_add(ctrl + kCtlStart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return uniform32(*s_tile);
 }
 
-// same, for a monotonic progress counter: wait until it has reached `value`
-__device__ __forceinline__ bool lds_wait_reached(const u32 *counter, u32 value, u32 *ctrl) {
-    if ((int)(lds_ld(counter) - value) < 0) {
-        __builtin_amdgcn_s_setprio(0);
-        for (u32 spins = 0; (int)(lds_ld(counter) - value) < 0;) {
-            if (++spins > kMaxSpins) {
-                atomicOr(ctrl + kCtlError, kErrTimeout);
-                return false;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        __builtin_amdgcn_s_setprio(1);
+__device__ __forceinline__ LaunchEpoch launch_epoch_begin(u32 *ctrl, u32 tile, u32 *scan_area, u64 scan_words, int keep_error) {
+    LaunchEpoch le;
+    const u32 stored = uniform32(ctrl[kCtlEpoch]);
+    const u32 magic = uniform32(ctrl[kCtlMagic]);
+    le.bad = magic != 0u && magic != kWorkspaceMagic; // neither a zeroed nor a used workspace
+    le.wrap = stored >= kEpochWrap;
+    le.epoch = (stored == 0u || le.wrap) ? 1u : stored;
+    if (le.bad) {
+        if (threadIdx.x == 0) atomicOr(ctrl + kCtlError, kErrWorkspace);
+        return le;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    return true;
+    if (le.wrap) {
+        const u32 wraps = uniform32(ctrl[kCtlWraps]);
+        if (tile == 0) {
+            for (u64 k = threadIdx.x; k < scan_words; k += blockDim.x)
+                __hip_atomic_store(scan_area + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_store(ctrl + kCtlClearDone, wraps + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (threadIdx.x == 0) {
+                u32 spins = 0;
+                while (__hip_atomic_load(ctrl + kCtlClearDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wraps + 1u) {
+                    if (++spins > kMaxSpins) {
+                        atomicOr(ctrl + kCtlError, kErrTimeout);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tile == 0 && threadIdx.x == 0 && !keep_error) {
+        // a new launch: forget the previous one's status.  Completed before this tile publishes anything, and every
+        // error of this launch is raised by a tile that has seen something published.
+        __hip_atomic_store(ctrl + kCtlError, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    return le;
 }
+
+// one lane of the last tile, after its scan: every other tile has published its granule, so it has read the epoch
+__device__ __forceinline__ void launch_epoch_end(u32 *ctrl, const LaunchEpoch &le) {
+    if (le.wrap) __hip_atomic_store(ctrl + kCtlWraps, ctrl[kCtlWraps] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ctrl + kCtlStart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // every tile number has been drawn
+    __hip_atomic_store(ctrl + kCtlMagic, kWorkspaceMagic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(ctrl + kCtlEpoch, le.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+constexpr int kAuxSc1 = 16; // buffer load cache policy: sc1 = agent scope (served past the XCD-private caches)
 
 // groups a compressed word expands to
 __device__ __forceinline__ u32 word_groups(u32 w) {
@@ -278,28 +197,6 @@ __device__ __forceinline__ u32 word_groups(u32 w) {
 constexpr int kExpandThreads = kExpandWaves * 64;                 // 256
 constexpr int kExpandWordsPerThread = kScanTileWords / kExpandThreads; // 16
 constexpr u32 kCoarse = kScanTileWords / 64;                      // coarse prefix: one entry per 64 words
-
-// The census counts what was resident at one moment; near the edge that depends on how the dispatcher happened to
-// place the wavefronts (measured: census 1184, runs above ~1060 workgroups lost a workgroup).  Keep a margin: only
-// whole multiples of the CU count are used, i.e. what EVERY compute unit can hold.
-[[maybe_unused]] inline int whole_per_cu(int resident) {
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (cus < 1) cus = 1;
-    return resident >= cus ? (resident / cus) * cus : resident;
-}
-
-[[maybe_unused]] inline int persistent_grid(const void *kernel, int threads, u64 n_tiles) {
-    int dev = 0, cus = 256, per_cu = 1;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    u64 g = (u64)cus * (u64)per_cu;
-    if (g > n_tiles) g = n_tiles;
-    if (g < 1) g = 1;
-    return (int)g;
-}
 
 } // namespace
 } // namespace wah

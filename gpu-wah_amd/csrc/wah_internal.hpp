@@ -22,11 +22,12 @@ constexpr uint32_t kSteps = 16; // 64 groups (one wavefront) per step
 // ---- inter-workgroup control block (uint32 words)
 // decode / aux kernels: zeroed before each launch.  compress: zeroed ONCE (wah_workspace_init_device), then kept up by
 // the kernel itself (launch epochs, see compress_tile_kernel).
-constexpr uint32_t kCtlStart = 0;        // arrival ticket: order in which workgroups start running (persistent kernels)
-constexpr uint32_t kCtlEpoch = 8;        // compress: epoch of the NEXT launch (0 = fresh workspace)
-constexpr uint32_t kCtlMagic = 9;        // compress: kWorkspaceMagic once a launch has completed (0 = fresh workspace)
-constexpr uint32_t kCtlWraps = 10;       // compress: how often the epoch space has been used up
-constexpr uint32_t kCtlClearDone = 11;   // compress: == kCtlWraps + 1 once tile 0 of a wrapping launch has cleared the scan area
+constexpr uint32_t kCtlStart = 0;        // arrival ticket: order in which workgroups start running (alone on its 128-byte line:
+                                         // every workgroup of a launch adds to it)
+constexpr uint32_t kCtlEpoch = 64;       // tile kernels: epoch of the NEXT launch (0 = fresh workspace); read-mostly line
+constexpr uint32_t kCtlMagic = 65;       // tile kernels: kWorkspaceMagic once a launch has completed (0 = fresh workspace)
+constexpr uint32_t kCtlWraps = 66;       // tile kernels: how often the epoch space has been used up
+constexpr uint32_t kCtlClearDone = 96;   // tile kernels: == kCtlWraps + 1 once tile 0 of a wrapping launch has cleared the scan area
 constexpr uint32_t kCtlError = 160;      // sticky error bits
 constexpr uint32_t kCtlCensus = 161;     // census mode: workgroups resident together
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
@@ -54,6 +55,10 @@ constexpr uint64_t kScanBlockTiles = 64 * 256;
 constexpr int kScanTileWords = 4096; // compressed words per tile (both decode passes)
 constexpr int kSumTilesPerGroup = 8;  // expand tiles per workgroup tile of the sums kernel (= its worker waves)
 constexpr int kExpandWaves = 4;      // wavefronts of an expand workgroup (each expands whole segments)
+// scan area of the sums kernel: one block per superrow of 64 rows x 256 workgroup tiles, 8-byte granules
+constexpr uint32_t kSumScanSlotsAt = 2 * 64 * 256;          // 32-bit words: the slots follow the superrow's granules
+constexpr uint32_t kSumScanBlockWords = 2 * 64 * 256 + 256; // granules + 65 slots, padded to 1 KiB
+constexpr uint64_t kSumScanBlockTiles = 64 * 256;
 
 struct CompressArgs {
     const uint32_t *in;
@@ -85,11 +90,10 @@ struct ScanArgs {
     uint64_t *info;      // [0] decoded words, [1] groups
     uint64_t *tile_base; // n_tiles + 1: groups in front of each tile, last = total
     uint32_t *ctrl;
-    uint32_t *gen_desc;  // generation rows (4-byte granules)
-    uint64_t *big;       // 64-bit side entries for totals that do not fit a granule
+    uint32_t *gen_desc;  // scan area: blocks of kSumScanBlockWords (see decode_sums_kernel)
+    uint64_t scan_words; // 32-bit words of the whole scan area
     uint8_t *tile_flags; // n_tiles: 1 = the tile contains a fill word of count 0
     int aligned16;
-    int census;
 };
 
 struct ExpandArgs {
@@ -148,8 +152,7 @@ struct PairCheck {
 hipError_t launch_compress(const CompressArgs &a, hipStream_t s); // pair mode when a.in2 != nullptr
 hipError_t launch_bitop_check(const uint64_t *info_a, const uint64_t *info_b, const uint32_t *ctrl_a, const uint32_t *ctrl_b, uint64_t groups,
                               uint32_t *ctrl, hipStream_t s);
-hipError_t launch_decode_sums(const ScanArgs &a, int grid, hipStream_t s);
-int decode_sums_grid(uint32_t *d_ctrl, hipStream_t s);
+hipError_t launch_decode_sums(const ScanArgs &a, hipStream_t s);
 hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t n_tiles, hipStream_t s);
 hipError_t launch_clear(void *p, size_t bytes, hipStream_t s);
 hipError_t launch_build_index(const uint32_t *comp, uint64_t c_words, const uint64_t *tile_base, const uint64_t *info, uint64_t *offsets,

@@ -94,11 +94,12 @@ size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_wo
  * `stream` is a hipStream_t passed as void* (NULL = the default stream).
  * ------------------------------------------------------------------------- */
 
-/* The compress workspace is initialised ONCE (all zero bytes: this call, or any memset) and then keeps itself up:
- * every launch stamps what it leaves there with a launch epoch, so nothing is cleared between launches, and one
- * workspace may serve bitmaps of different sizes (up to the one it was sized for) in turn -- but only one launch at a
- * time.  A workspace that is neither zeroed nor left by an earlier launch is reported as WAH_ERR_WORKSPACE by
- * wah_compress_status().  Asynchronous on `stream`. */
+/* A workspace (compress, decompress, merge_fills) is initialised ONCE (all zero bytes: this call, or any memset) and
+ * then keeps itself up: every launch stamps what it leaves there with a launch epoch, so nothing is cleared between
+ * launches, and one workspace may serve inputs of different sizes (up to the one it was sized for) in turn -- but only
+ * one launch at a time.  A workspace that is neither zeroed nor left by an earlier launch is reported as
+ * WAH_ERR_WORKSPACE by the status calls.  (The `scratch` of the wah_bitop_* calls needs no initialisation.)
+ * Asynchronous on `stream`. */
 int wah_workspace_init_device(void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* d_in: n_words words, 16-byte aligned.  d_out: room for out_capacity_words
