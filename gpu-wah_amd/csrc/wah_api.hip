@@ -78,6 +78,8 @@ DecodeLayout decode_layout(uint64_t c_words) {
     return l;
 }
 
+int status_from_bits(uint32_t err);
+
 // status word of a launch, and optionally `n_vals` 64-bit results of it, in ONE round trip to the device
 int read_status(void *d_workspace, void *stream, const uint64_t *d_vals = nullptr, uint64_t *vals = nullptr, int n_vals = 0) {
     uint32_t err = 0;
@@ -90,6 +92,10 @@ int read_status(void *d_workspace, void *stream, const uint64_t *d_vals = nullpt
         set_err("status read-back", e);
         return WAH_ERR_HIP;
     }
+    return status_from_bits(err);
+}
+
+int status_from_bits(uint32_t err) {
     if (err & wah::kErrWorkspace) {
         set_err("compress workspace was not initialised (wah_workspace_init_device)");
         return WAH_ERR_WORKSPACE;
@@ -109,10 +115,37 @@ int read_status(void *d_workspace, void *stream, const uint64_t *d_vals = nullpt
     return WAH_OK;
 }
 
+// Host-pointer entry points: the results of a launch (kCtlResult) lie beside its error word, so one 32-byte copy into
+// page-locked memory + one stream synchronisation is the whole read-back (two pageable copies cost 2 x 15 us more).
+int read_status_packed(void *d_workspace, uint32_t *pinned, uint64_t *vals, int n_vals) {
+    hipError_t e = hipMemcpyAsync(pinned, static_cast<uint32_t *>(d_workspace) + wah::kCtlError, 8 * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        set_err("status read-back", e);
+        return WAH_ERR_HIP;
+    }
+    for (int i = 0; i < n_vals; ++i) std::memcpy(&vals[i], pinned + (wah::kCtlResult - wah::kCtlError) + 2 * i, sizeof(uint64_t));
+    return status_from_bits(pinned[0]);
+}
+
+// ... or without any copy: the last tile of the launch wrote {1 | error bits << 32, results...} into page-locked host
+// memory; wait for the stream and read them.  A launch that ended early (unusable workspace) leaves the mark unset.
+int wait_host_result(volatile uint64_t *result, void *d_workspace, uint32_t *pinned, uint64_t *vals, int n_vals) {
+    const hipError_t e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) {
+        set_err("waiting for the device", e);
+        return WAH_ERR_HIP;
+    }
+    if (!(result[0] & 1ull)) return read_status_packed(d_workspace, pinned, vals, n_vals);
+    for (int i = 0; i < n_vals; ++i) vals[i] = result[1 + i];
+    return status_from_bits((uint32_t)(result[0] >> 32));
+}
+
 // Device buffers of the host-pointer entry points.  The reference allocates and frees them inside every call
 // (compress.cu:57-114,177-202; decompress.cu:34-54,124-131), which puts hipMalloc/hipFree of up to two bitmap-sized
 // buffers -- milliseconds, and cold address translations for the kernels that follow -- into the timings it
-// reports.  Here the buffers are kept between calls: grow-only, one set per process, the call holds the set's
+// reports.  Here the buffers are kept between calls: grow-only, one set per device, the call holds the set's
 // mutex.  wah_host_cache_release() frees them; WAH_HOST_CACHE=0 in the environment restores allocate-and-free.
 struct HostCache {
     static constexpr int kSlots = 6;
@@ -120,6 +153,8 @@ struct HostCache {
     void *buf[kSlots] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t cap[kSlots] = {0, 0, 0, 0, 0, 0};
     int device = -1; // the device the kept buffers live on
+    uint32_t *pinned = nullptr; // 64 bytes of page-locked host memory: where status + sizes of a launch land (copied, or
+                                // written by the kernel itself: CompressArgs::host_result)
     void release_locked() {
         for (int i = 0; i < kSlots; ++i) {
             if (buf[i]) (void)hipFree(buf[i]);
@@ -128,9 +163,17 @@ struct HostCache {
         }
     }
 };
-HostCache &host_cache() {
-    static HostCache *c = new HostCache; // never destroyed: the HIP runtime may be gone before static destructors run
-    return *c;
+// one set per device: host threads that drive different GPUs (one host thread per GPU) neither
+// share a mutex nor evict each other's buffers
+constexpr int kMaxDevices = 64;
+HostCache &host_cache(int device) {
+    static HostCache *c = new HostCache[kMaxDevices]; // never destroyed: the HIP runtime may be gone before static destructors run
+    return c[device >= 0 && device < kMaxDevices ? device : 0];
+}
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return dev;
 }
 bool host_cache_enabled() {
     static const bool on = [] {
@@ -143,7 +186,7 @@ bool host_cache_enabled() {
 // RAII bundle for the host-pointer paths: owns the timing events and the call's claim on the buffer set
 // (or, without the cache, frees whatever was allocated, like the error exits of compress.cu:89-114).
 struct HostCall {
-    HostCache &cache = host_cache();
+    HostCache &cache = host_cache(current_device());
     std::unique_lock<std::mutex> lock{cache.m};
     const bool keep = host_cache_enabled();
     hipEvent_t ev[2] = {nullptr, nullptr};
@@ -180,9 +223,10 @@ struct HostCall {
     bool init() {
         int dev = -1;
         if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (dev != cache.device) { // the caller moved to another GPU: buffers of the old one are of no use here
-            cache.release_locked();
-            cache.device = dev;
+        cache.device = dev;
+        if (!cache.pinned && hipHostMalloc(reinterpret_cast<void **>(&cache.pinned), 128, hipHostMallocDefault) != hipSuccess) {
+            cache.pinned = nullptr;
+            return false;
         }
         return hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
     }
@@ -288,9 +332,15 @@ const char *wah_last_error(void) { return g_err; }
 const char *wah_version(void) { return "wah-mi355x 0.1 gfx950"; }
 void wah_free(void *p) { std::free(p); }
 void wah_host_cache_release(void) {
-    HostCache &c = host_cache();
-    std::lock_guard<std::mutex> g(c.m);
-    c.release_locked();
+    for (int d = 0; d < kMaxDevices; ++d) {
+        HostCache &c = host_cache(d);
+        std::lock_guard<std::mutex> g(c.m);
+        if (c.device < 0) continue; // never used
+        int prev = 0;
+        const bool switched = hipGetDevice(&prev) == hipSuccess && prev != c.device && hipSetDevice(c.device) == hipSuccess;
+        c.release_locked();
+        if (switched) (void)hipSetDevice(prev);
+    }
 }
 
 uint64_t wah_max_compressed_words(uint64_t n_words) { return (32u * n_words + 30u) / 31u; }
@@ -306,7 +356,8 @@ size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_wo
 // launch, which makes it a fresh workspace every time -- and keep whatever error an upstream pass leaves in it.
 static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int op, const wah::PairCheck *check, uint64_t n_words,
                                 uint32_t *d_out, uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_segment_offsets,
-                                void *d_workspace, size_t workspace_bytes, void *stream, bool clear_first) {
+                                void *d_workspace, size_t workspace_bytes, void *stream, bool clear_first,
+                                uint64_t *host_result = nullptr) {
     g_err[0] = 0;
     if (!d_out_words || !d_workspace || (n_words && (!d_in || !d_out))) {
         set_err("null pointer");
@@ -359,6 +410,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
     a.scan_words = (l.total - l.desc_off) / sizeof(uint32_t);
     a.keep_error = clear_first ? 1 : 0;
+    a.host_result = host_result;
     {
         static const uint32_t tune = [] {
             const char *e = std::getenv("WAH_TUNE");
@@ -417,7 +469,7 @@ int wah_decompress_status(void *d_workspace, void *stream) { return read_status(
 // front of the launch, which makes it a fresh workspace every time.
 static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                          uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream, bool do_scan,
-                         bool do_expand, bool clear_first = false) {
+                         bool do_expand, bool clear_first = false, uint64_t *host_result = nullptr) {
     g_err[0] = 0;
     if (!d_out_info || !d_workspace || (c_words && !d_comp) || (do_expand && out_capacity_words && !d_out)) {
         set_err("null pointer");
@@ -461,6 +513,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
             a.scan_words = l.scan_bytes / sizeof(uint32_t);
             a.tile_flags = reinterpret_cast<uint8_t *>(ws + l.flags_off);
             a.aligned16 = aligned16(d_comp) ? 1 : 0;
+            a.host_result = host_result;
             e = wah::launch_decode_sums(a, s);
             if (e != hipSuccess) {
                 set_err("decode sums kernel launch", e);
@@ -920,24 +973,26 @@ uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *ou
     hc.start();
     const uint64_t cap = wah_max_compressed_words(n_words);
     const size_t ws_bytes = wah_compress_workspace_bytes(n_words);
-    void *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr, *d_cnt = nullptr;
+    void *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr;
     if (!hc.alloc(0, &d_in, n_words * sizeof(uint32_t), "space for the data")) return nullptr;
     if (!hc.alloc(1, &d_out, cap * sizeof(uint32_t), "space for the compressed output")) return nullptr;
     bool fresh_ws = false;
     if (!hc.alloc(2, &d_ws, ws_bytes, "workspace", &fresh_ws)) return nullptr;
     // the compress workspace is zeroed once; from then on the kernel keeps it up itself (launch epochs)
     if (fresh_ws && wah_workspace_init_device(d_ws, ws_bytes, nullptr) != WAH_OK) return nullptr;
-    if (!hc.alloc(3, &d_cnt, sizeof(uint64_t), "output size")) return nullptr;
+    uint64_t *d_cnt = reinterpret_cast<uint64_t *>(static_cast<uint32_t *>(d_ws) + wah::kCtlResult); // beside the error word
     if (n_words && !hip_ok(hipMemcpy(d_in, data_host, n_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
         return nullptr;
     t_in = hc.stop();
 
     // phase 2: device work (compress.cu:125-172)
     hc.start();
-    int rc = wah_compress_device(static_cast<uint32_t *>(d_in), n_words, static_cast<uint32_t *>(d_out), cap,
-                                 static_cast<uint64_t *>(d_cnt), d_ws, ws_bytes, nullptr);
+    uint64_t *const host_result = reinterpret_cast<uint64_t *>(hc.cache.pinned) + 4; // behind the copy's landing area
+    host_result[0] = 0;
+    int rc = compress_device_impl(static_cast<uint32_t *>(d_in), nullptr, 0, nullptr, n_words, static_cast<uint32_t *>(d_out), cap, d_cnt,
+                                  nullptr, d_ws, ws_bytes, nullptr, false, n_words ? host_result : nullptr);
     uint64_t c = 0;
-    if (rc == WAH_OK) rc = read_status(d_ws, nullptr, static_cast<const uint64_t *>(d_cnt), &c, 1); // status + size: one sync
+    if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws, hc.cache.pinned, &c, 1); // status + size: one wait, no copy
     if (rc != WAH_OK) {
         std::fprintf(stderr, "wah: compress failed: %s\n", g_err);
         return nullptr;
@@ -984,24 +1039,26 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
 
     // phase 1: allocate + H2D (decompress.cu:34-54)
     hc.start();
-    void *d_comp = nullptr, *d_info = nullptr, *d_ws0 = nullptr;
+    void *d_comp = nullptr, *d_ws0 = nullptr;
     const size_t ws0 = wah_decompress_workspace_bytes(c_words, 0);
     if (!hc.alloc(1, &d_comp, c_words * sizeof(uint32_t), "space for the compressed data")) return nullptr;
-    if (!hc.alloc(3, &d_info, 2 * sizeof(uint64_t), "output size")) return nullptr;
     bool fresh_ws = false;
     if (!hc.alloc(4, &d_ws0, ws0, "scan workspace", &fresh_ws)) return nullptr;
     // zeroed once; from then on the sums kernel keeps it up itself (launch epochs)
     if (fresh_ws && wah_workspace_init_device(d_ws0, ws0, nullptr) != WAH_OK) return nullptr;
+    uint64_t *d_info = reinterpret_cast<uint64_t *>(static_cast<uint32_t *>(d_ws0) + wah::kCtlResult); // beside the error word
     if (c_words && !hip_ok(hipMemcpy(d_comp, comp_host, c_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
         return nullptr;
     t_in = hc.stop();
 
     // phase 2: device work (decompress.cu:56-122): size scan, allocate, scan + expand
     hc.start();
-    int rc = wah_decompress_scan_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint64_t *>(d_info), d_ws0,
-                                        ws0, nullptr);
+    uint64_t *const host_result = reinterpret_cast<uint64_t *>(hc.cache.pinned) + 4; // behind the copy's landing area
+    host_result[0] = 0;
+    int rc = decode_common(static_cast<uint32_t *>(d_comp), c_words, nullptr, 0, d_info, d_ws0, ws0, nullptr, true, false, false,
+                           c_words ? host_result : nullptr);
     uint64_t info[2] = {0, 0};
-    if (rc == WAH_OK) rc = read_status(d_ws0, nullptr, static_cast<const uint64_t *>(d_info), info, 2); // status + sizes: one sync
+    if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws0, hc.cache.pinned, info, 2); // status + sizes: one wait, no copy
     if (rc != WAH_OK) {
         std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
         return nullptr;
@@ -1010,9 +1067,9 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     void *d_out = nullptr;
     if (!hc.alloc(0, &d_out, n_out * sizeof(uint32_t), "space for the result")) return nullptr;
     // the tile bases of the scan are still in the workspace: expand only
-    rc = wah_decompress_expand_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(d_out), n_out,
-                                      static_cast<uint64_t *>(d_info), d_ws0, ws0, nullptr);
-    if (rc == WAH_OK) rc = wah_decompress_status(d_ws0, nullptr);
+    rc = wah_decompress_expand_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(d_out), n_out, d_info,
+                                      d_ws0, ws0, nullptr);
+    if (rc == WAH_OK) rc = read_status_packed(d_ws0, hc.cache.pinned, nullptr, 0);
     if (rc != WAH_OK) {
         std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
         return nullptr;

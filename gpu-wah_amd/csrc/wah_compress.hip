@@ -17,6 +17,8 @@
 //   * output offsets come from a one-hop "row scan" over 4-byte {epoch, count} granules written and read with
 //     agent-scope accesses (correct across the 8 non-coherent XCD L2s), instead of thrust::exclusive_scan + moveData
 //     (compress.cu:133-166, kernels.cu:273-280); nothing is persistent and nothing is cleared between launches.
+#include <cstdlib>
+
 #include "wah_device.hpp"
 
 namespace wah {
@@ -577,6 +579,11 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
                 *a.out_words = end;
                 if (a.seg_offsets) a.seg_offsets[a.n_segments] = end;
                 if (end > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+                if (a.host_result) {
+                    // every scan of the launch can complete now (this one needed all of them), so the error word is final
+                    a.host_result[1] = end;
+                    a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
+                }
                 launch_epoch_end(a.ctrl, le); // every other tile has published, so it has read the epoch: advance it
             }
         }
@@ -649,8 +656,15 @@ hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {
 
 // segments per wavefront for a bitmap of n_segments: enough tiles to occupy the chip first, long tiles after that
 uint32_t compress_wave_segs(uint64_t n_segments) {
-    if (n_segments <= 6144) return 1;  // 256 CUs x 3 workgroups x 8 waves: one round of one-segment waves
-    if (n_segments <= 24576) return 2;
+    static const int forced = [] { // experiments only
+        const char *e = std::getenv("WAH_WAVE_SEGS");
+        return e ? std::atoi(e) : 0;
+    }();
+    if (forced == 1 || forced == 2 || forced == kCompressMaxWaveSegs) return (uint32_t)forced;
+    // measured on 4 MiB .. 512 MiB bitmaps (tools/scratch/size_s_sweep.py): 4 MiB 8.0 / 8.6 / 12.9 us with 1 / 2 / 5
+    // segments per wave, 16 MiB 16.2 / 13.1 / 15.0, 32 MiB 27.5 / 21.9 / 17.8, 128 MiB 76.6 / 57.2 / 50.6
+    if (n_segments <= 2400) return 1;
+    if (n_segments <= 6000) return 2;
     return (uint32_t)kCompressMaxWaveSegs;
 }
 

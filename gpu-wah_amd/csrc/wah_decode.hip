@@ -244,6 +244,11 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
             a.tile_base[n_tiles] = end;
             a.info[1] = end;
             a.info[0] = (31ull * end + 31ull) / 32ull; // decompress.cu:84-93
+            if (a.host_result) { // every scan of the launch can complete now, so the error word is final
+                a.host_result[1] = (31ull * end + 31ull) / 32ull;
+                a.host_result[2] = end;
+                a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
+            }
             launch_epoch_end(a.ctrl, le);
         }
     }

@@ -29,7 +29,8 @@ constexpr uint32_t kCtlMagic = 65;       // tile kernels: kWorkspaceMagic once a
 constexpr uint32_t kCtlWraps = 66;       // tile kernels: how often the epoch space has been used up
 constexpr uint32_t kCtlClearDone = 96;   // tile kernels: == kCtlWraps + 1 once tile 0 of a wrapping launch has cleared the scan area
 constexpr uint32_t kCtlError = 160;      // sticky error bits
-constexpr uint32_t kCtlCensus = 161;     // census mode: workgroups resident together
+constexpr uint32_t kCtlResult = 162;     // host-pointer entry points: two 64-bit results of the launch live here, beside the
+                                         // error word, so that ONE 32-byte copy brings status and sizes to the host
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
 constexpr uint32_t kErrTimeout = 1u;     // a bounded wait expired
 constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity
@@ -80,6 +81,8 @@ struct CompressArgs {
     uint32_t *gen_desc;    // scan area: blocks of kScanBlockWords (see compress_tile_kernel)
     uint64_t scan_words;   // 32-bit words of the whole scan area
     int keep_error;        // 1: the control block was cleared by the caller and may already hold an upstream error
+    uint64_t *host_result; // optional, page-locked HOST memory: [0] = 1 | error bits << 32, [1] = C, written by the last tile
+                           // (the host-pointer entry points read them after one event wait, without a copy)
     uint32_t tune;         // experiments only (WAH_TUNE)
 };
 
@@ -94,6 +97,7 @@ struct ScanArgs {
     uint64_t scan_words; // 32-bit words of the whole scan area
     uint8_t *tile_flags; // n_tiles: 1 = the tile contains a fill word of count 0
     int aligned16;
+    uint64_t *host_result; // optional, page-locked HOST memory: [0] = 1 | error bits << 32, [1..2] = info, by the last tile
 };
 
 struct ExpandArgs {

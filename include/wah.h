@@ -64,7 +64,7 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
 /* free() for buffers returned above (source.cpp:108-109, tests.h:22 use free()). */
 void wah_free(void *p);
 
-/* The two entry points above keep their device buffers between calls (grow-only, one set per process; calls
+/* The two entry points above keep their device buffers between calls (grow-only, one set per device; calls
  * from several threads take turns), where the reference allocates and frees inside every call
  * (compress.cu:57-114,177-202; decompress.cu:34-54,124-131).  This returns them to the device now; setting
  * WAH_HOST_CACHE=0 in the environment restores allocate-and-free per call. */
