@@ -70,9 +70,11 @@ __device__ __forceinline__ void sum_scan_issue(u32 *block, u32 row_in_super, u32
     }
 }
 
+// kWaveTiles: expand tiles a wavefront sums one after the other (long streams: 4, so that ticket, barrier and scan are
+// paid once per 128 KiB... 512 KiB of stream; short streams: 1, more workgroups)
+template <u32 kWaveTiles>
 __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanArgs a) {
-    __shared__ u64 s_part[kSumWaves];
-    __shared__ u32 s_empty[kSumWaves];
+    __shared__ u64 s_part[kSumWaves * kWaveTiles];
     __shared__ u32 s_tile;
 
     const u32 lane = lane_id();
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
     const u32 wt = draw_tile(a.ctrl, &s_tile);     // workgroup tile: arrival order (wah_device.hpp)
     const u32 n_tiles = (u32)a.n_tiles;            // expand tiles (4096 words)
     const u32 n_wg_tiles = gridDim.x;
-    const u32 et = wt * kSumWaves + wave;          // this wave's expand tile
+    const u32 et0 = (wt * kSumWaves + wave) * kWaveTiles; // this wave's expand tiles: et0 .. et0 + kWaveTiles - 1
 
     const LaunchEpoch le = launch_epoch_begin(a.ctrl, wt, a.gen_desc, a.scan_words, 0);
     if (le.bad) {
@@ -89,49 +91,70 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
     }
     const u32 epoch = le.epoch;
 
-    // ---- this wave's expand tile: sum of the group counts ----------------------------------------------------------
+    // ---- this wave's expand tiles: sums of the group counts -----------------------------------------------------------
     // A fill word of count 0 expands to nothing; the reference decoder steps over it (kernels.cu:332-354).  The expand
     // kernel's rank arithmetic assumes that every word owns at least one group, so every tile is checked here and
     // expand takes its index-map route for the tiles concerned (tile_flags).
+    // Rolling rounds of 1024 words (four coalesced 1 KiB loads per round, the next round in flight while this one is
+    // summed): 4 KiB per wave in flight keeps the memory pipeline busy without flooding it.
+    const bool fast = a.aligned16 != 0;
+    auto round_whole = [&](u32 rd) { // round rd of the wave's tiles lies wholly inside the stream
+        return fast && (u64)et0 * kScanTileWords + (u64)(rd + 1u) * 1024u <= a.c_words;
+    };
+    auto issue_round = [&](u32 rd, u32x4 (&v)[4]) {
+        const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.comp + (u64)et0 * kScanTileWords + (u64)rd * 1024u, 4096u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + 1024u * k, 0, 0);
+    };
+    constexpr u32 kRounds = 4u * kWaveTiles;
+    u32x4 cur[4], nxt[4];
+    if (round_whole(0)) issue_round(0, cur);
     u64 mine = 0;
     bool has_empty = false;
-    if (et < n_tiles) {
-        const u64 w0 = (u64)et * kScanTileWords;
-        if (a.aligned16 && w0 + kScanTileWords <= a.c_words) {
-            const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.comp + w0, kScanTileWords * 4u);
-            u32x4 v[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + 1024u * k, 0, 0);
-            u32 lo = 1;
+    for (u32 rd = 0; rd < kRounds; ++rd) {
+        const u32 et = et0 + rd / 4u;
+        if (et < n_tiles) {
+            if (round_whole(rd)) {
+                if (rd + 1u < kRounds && round_whole(rd + 1u)) issue_round(rd + 1u, nxt);
+                u32 lo = 1;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { // four counts of < 2^30 each fit 32 bits
-                const u32 nx = word_groups(v[k].x), ny = word_groups(v[k].y), nz = word_groups(v[k].z), nw = word_groups(v[k].w);
-                mine += (u64)(nx + ny + nz + nw);
-                lo = min(min(lo, min(nx, ny)), min(nz, nw));
-            }
-            has_empty = lo == 0u;
-        } else { // the stream's last tile, or a stream that is only 4-byte aligned: word by word, bounds checked
-            for (u32 i = lane; i < (u32)kScanTileWords; i += 64u) {
-                if (w0 + i < a.c_words) {
-                    const u32 n = word_groups(a.comp[w0 + i]);
-                    mine += n;
-                    has_empty |= n == 0u;
+                for (int k = 0; k < 4; ++k) { // four counts of < 2^30 each fit 32 bits
+                    const u32 nx = word_groups(cur[k].x), ny = word_groups(cur[k].y), nz = word_groups(cur[k].z), nw = word_groups(cur[k].w);
+                    mine += (u64)(nx + ny + nz + nw);
+                    lo = min(min(lo, min(nx, ny)), min(nz, nw));
+                }
+                has_empty |= lo == 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+            } else { // the stream's last rounds, or a stream that is only 4-byte aligned: word by word, bounds checked
+                const u64 w0 = (u64)et0 * kScanTileWords + (u64)rd * 1024u;
+                for (u32 i = lane; i < 1024u; i += 64u) {
+                    if (w0 + i < a.c_words) {
+                        const u32 n = word_groups(a.comp[w0 + i]);
+                        mine += n;
+                        has_empty |= n == 0u;
+                    }
                 }
             }
         }
-    }
-    const u64 wave_total = uniform64(wave_sum(mine));
-    const bool any_empty = __any(has_empty);
-    if (lane == 0) {
-        s_part[wave] = wave_total;
-        s_empty[wave] = any_empty ? 1u : 0u;
-        if (et < n_tiles) a.tile_flags[et] = any_empty ? 1 : 0;
+        if (rd % 4u == 3u) { // a tile is complete
+            const u64 tile_total = uniform64(wave_sum(mine));
+            const bool any_empty = __any(has_empty);
+            if (lane == 0) {
+                s_part[wave * kWaveTiles + rd / 4u] = tile_total;
+                if (et < n_tiles) a.tile_flags[et] = any_empty ? 1 : 0;
+            }
+            mine = 0;
+            has_empty = false;
+        }
     }
     __syncthreads();
     if (wave != 0) return;
 
     // ---- wave 0: the workgroup tile's total goes out, then the groups in front of it ---------------------------------
-    const u64 part = lane < kSumWaves ? s_part[lane] : 0ull;
+    static_assert(kSumWaves * kWaveTiles <= 64, "one lane per expand tile of the workgroup tile");
+    const u64 part = lane < kSumWaves * kWaveTiles ? s_part[lane] : 0ull;
     const u64 incl_part = wave_scan_incl(part, lane);
     u64 total = uniform64(__shfl(incl_part, 63));
     bool overflow = total >= kSumSaturate;
@@ -233,8 +256,8 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
     const u64 base = sat_add(sat_add(sum_c, sum_b), sum_a);
     const u64 end = sat_add(base, total);
     overflow |= end >= kSumSaturate;
-    // lane w: groups in front of expand tile wt * kSumWaves + w
-    if (lane < kSumWaves && et + lane < n_tiles) a.tile_base[et + lane] = base + (incl_part - part);
+    // lane w: groups in front of expand tile et0 + w (wave 0: et0 = the workgroup tile's first expand tile)
+    if (lane < kSumWaves * kWaveTiles && et0 + lane < n_tiles) a.tile_base[et0 + lane] = base + (incl_part - part);
     if (lane == 0) {
         if (overflow) atomicOr(a.ctrl + kCtlError, kErrStream);
         if (idx == kSumRowTiles - 1u && row - row0 == kSumSuperRows - 1u) // last tile of a superrow
@@ -875,8 +898,14 @@ __global__ __launch_bounds__(kSegDecodeWaves * 64, 6) void bitop_many_segments_k
 } // namespace
 
 hipError_t launch_decode_sums(const ScanArgs &a, hipStream_t s) {
-    const u64 wg_tiles = (a.n_tiles + kSumWaves - 1) / kSumWaves;
-    hipLaunchKernelGGL(decode_sums_kernel, dim3((unsigned)wg_tiles), dim3(kSumWaves * 64), 0, s, a);
+    // long streams: four expand tiles per wave (ticket, barrier and scan once per 512 KiB); short ones: more workgroups
+    if (a.n_tiles >= 16384) {
+        const u64 wg_tiles = (a.n_tiles + kSumWaves * 4 - 1) / (kSumWaves * 4);
+        hipLaunchKernelGGL(decode_sums_kernel<4>, dim3((unsigned)wg_tiles), dim3(kSumWaves * 64), 0, s, a);
+    } else {
+        const u64 wg_tiles = (a.n_tiles + kSumWaves - 1) / kSumWaves;
+        hipLaunchKernelGGL(decode_sums_kernel<1>, dim3((unsigned)wg_tiles), dim3(kSumWaves * 64), 0, s, a);
+    }
     return hipGetLastError();
 }
 

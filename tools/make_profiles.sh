@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the round's profile evidence on the GPU box into gpurun_out/profiles_rNN/ (copy the summaries to profiles/).
 # usage: tools/make_profiles.sh r01
-tag=${1:-r01}
+tag=${1:-r02}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 out=$R/gpurun_out/profiles_$tag
 rm -rf $out; mkdir -p $out
@@ -23,7 +23,7 @@ out = "$out"
 summary = {}
 lines = []
 for wl in ("sparse", "clustered", "dense"):
-    # kernel-trace: per-kernel durations (census launches = the short first dispatches are excluded)
+    # kernel-trace: per-kernel durations
     d = collections.defaultdict(list)
     for f in glob.glob(f"{out}/kt_{wl}/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
@@ -32,8 +32,6 @@ for wl in ("sparse", "clustered", "dense"):
             d[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     lines.append(f"== {wl}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload {wl}")
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
-        if k in ("compress_kernel", "decode_sums_kernel"):
-            v = sorted(v)[1:] if len(v) > 1 else v  # drop the residency-census launch (about 35 us)
         lines.append(f"  {k:36s} calls {len(v):4d}  avg {sum(v)/len(v):10.1f} us  min {min(v):10.1f}  max {max(v):10.1f}  total {sum(v):12.1f}")
     # PMC: bytes per launch
     tr = {}
@@ -45,8 +43,6 @@ for wl in ("sparse", "clustered", "dense"):
                 if m and r["Counter_Name"] == c:
                     agg[m.group(1)].append(float(r["Counter_Value"]))
         for k, v in agg.items():
-            if k in ("compress_kernel", "decode_sums_kernel") and len(v) > 1:
-                v = sorted(v)[1:]  # drop the census launch
             tr.setdefault(k, {})[c] = sum(v) / len(v)
     lines.append(f"  PMC (KiB per launch, raw counters): " + json.dumps(tr))
     def hbm(k):
@@ -54,7 +50,7 @@ for wl in ("sparse", "clustered", "dense"):
         t = tr.get(k, {})
         return (2.0 * t.get("FETCH_SIZE", 0) + t.get("WRITE_SIZE", 0)) * 1024.0
     summary[wl] = {
-        "compress_bytes_per_launch": hbm("compress_kernel"),
+        "compress_bytes_per_launch": hbm("compress_tile_kernel"),
         "decompress_bytes_per_launch": hbm("decode_sums_kernel") + hbm("decode_expand_kernel"),
         "decompress_indexed_bytes_per_launch": hbm("decode_segments_kernel"),
         "source": f"profiles/{os.path.basename(out).replace('profiles_', '')}_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md",
