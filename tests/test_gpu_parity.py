@@ -436,7 +436,7 @@ def torch_pad(t, n):
 
 # ---------------------------------------------------------------- API behaviour
 def test_reusable_workspace_and_indexed_output(wah, oracle):
-    """Same DeviceCompressor run repeatedly (control block re-zeroed every launch) + the segment index."""
+    """Same DeviceCompressor run repeatedly (nothing is cleared between launches: launch epochs) + the segment index."""
     import torch
 
     n = 992 * 1000
@@ -455,9 +455,121 @@ def test_reusable_workspace_and_indexed_output(wah, oracle):
     torch.cuda.synchronize()
 
 
+def test_workspace_serves_different_sizes_in_turn(wah, oracle):
+    """One workspace, bitmaps of very different sizes one after the other (1, 2 and 5 segments per wavefront, so the
+    tile <-> granule mapping changes between launches): nothing is cleared in between, launch epochs keep the
+    launches apart (include/wah.h: wah_workspace_init_device)."""
+    big = 992 * 30000
+    comp = wah.DeviceCompressor(big)
+    dec = wah.DeviceDecompressor(wah.max_compressed_words(big), big + 1)
+    for i, n in enumerate((big, 992 * 7, 992 * 3000 + 5, 31, big, 992 * 5000, 1)):
+        data = oracle.gen_uniform(n, 100 + i, (0.01, 0.5, 0.0001)[i % 3])
+        comp.run(_dev(data), n_words=n)
+        got = comp.result()
+        assert np.array_equal(_host(got), oracle.compress(data)), n
+        dec.run(got.clone(), c_words=got.numel())
+        assert np.array_equal(_host(dec.result())[:n], data), n
+
+
+def test_launch_epoch_wraps_around(wah, oracle):
+    """The epoch that stamps a launch's granules has 16 bits.  Start a workspace just below the end of the range: the
+    launches that cross it (the wrapping one has tile 0 clear the scan area while the others wait) give the same
+    stream as any other launch, for the compressor and for the sums kernel of the decoder."""
+    import torch
+
+    n = 992 * 20000
+    data = oracle.gen_uniform(n, 5, 0.02)
+    want = oracle.compress(data)
+    d = _dev(data)
+    comp = wah.DeviceCompressor(n)
+    dec = wah.DeviceDecompressor(len(want), n + 1)
+    for ws in (comp.workspace, dec.workspace):
+        ctrl = ws[:1024].view(torch.int32)
+        ctrl[64] = 65533            # kCtlEpoch: two launches below the wrap value
+        ctrl[65] = 0x57414832       # kCtlMagic: "a launch has completed"
+    stream = _dev(want)
+    for _ in range(5):
+        comp.run(d)
+        assert np.array_equal(_host(comp.result()), want)
+        dec.run(stream)
+        assert np.array_equal(_host(dec.result())[:n], data)
+    assert int(comp.workspace[:1024].view(torch.int32)[64].item()) in (2, 3, 4)  # wrapped, and counting again
+    assert int(comp.workspace[:1024].view(torch.int32)[66].item()) == 1          # kCtlWraps
+
+
+def test_uninitialised_workspace_is_reported(wah, oracle):
+    """A workspace that is neither zeroed nor left by an earlier launch: WAH_ERR_WORKSPACE, not a wrong stream."""
+    import torch
+
+    n = 992 * 100
+    data = oracle.gen_uniform(n, 9, 0.1)
+    comp = wah.DeviceCompressor(n)
+    comp.workspace.fill_(0x5A)
+    comp.run(_dev(data))
+    with pytest.raises(wah.WahError, match="not initialised"):
+        comp.status()
+    # wah_workspace_init_device makes it usable again
+    assert wah.lib().wah_workspace_init_device(comp.workspace.data_ptr(), comp.ws_bytes, None) == 0
+    comp.run(_dev(data))
+    assert np.array_equal(_host(comp.result()), oracle.compress(data))
+    dec = wah.DeviceDecompressor(comp.count.item(), n + 1)
+    dec.workspace.fill_(0x5A)
+    dec.run(comp.out)
+    with pytest.raises(wah.WahError, match="not initialised"):
+        dec.status()
+    torch.cuda.synchronize()
+
+
+def test_two_host_threads_two_streams_one_device(wah, oracle):
+    """Two host threads, each with its own stream, compressor and decompressor, hammer the same GPU at once (SURVEY.md
+    section 8e: one host thread per GPU stream).  The tile kernels of the two streams run side by side; each tile only
+    waits for tiles that are already running (arrival tickets), so neither starves the other, and every result is
+    bit-exact.  The host-pointer entry points are called from both threads as well (one buffer set per device, calls
+    take turns)."""
+    import threading
+
+    import torch
+
+    n = 992 * 40000
+    inputs = [oracle.gen_uniform(n, 21, 0.01), oracle.gen_clustered(n, 22)]
+    wants = [oracle.compress(x) for x in inputs]
+    small = oracle.gen_uniform(992 * 50, 23, 0.2)
+    small_want = oracle.compress(small)
+    errors = []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                d = _dev(inputs[k])
+                comp = wah.DeviceCompressor(n)
+                dec = wah.DeviceDecompressor(len(wants[k]), n + 1)
+                for it in range(12):
+                    comp.run(d, stream=stream)
+                    dec.run(comp.out, c_words=len(wants[k]), stream=stream)
+                    if it % 4 == 3:
+                        comp.status(stream)
+                        dec.status(stream)
+                        assert int(comp.count.item()) == len(wants[k])
+                        assert np.array_equal(_host(comp.out[: len(wants[k])]), wants[k])
+                        assert np.array_equal(_host(dec.out[:n]), inputs[k])
+                        assert np.array_equal(wah.compress(small), small_want)
+                stream.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in threads), "a worker thread is stuck"
+    assert not errors, errors
+
+
 def test_device_api_is_graph_capturable(wah, oracle):
-    """Nothing is allocated and nothing synchronises inside the device-pointer calls (after the first call on a device,
-    which runs the residency census): a compress + decompress pair can be captured into a HIP graph and replayed."""
+    """Nothing is allocated and nothing synchronises inside the device-pointer calls: a compress + decompress pair can be
+    captured into a HIP graph and replayed (every replay advances the workspaces' launch epochs like a plain launch)."""
     import torch
 
     n = 992 * 3000 + 5
@@ -466,7 +578,7 @@ def test_device_api_is_graph_capturable(wah, oracle):
     d_in = a.clone()
     comp = wah.DeviceCompressor(n)
     dec = wah.DeviceDecompressor(comp.capacity, n + 1)
-    comp.run(d_in)  # first call: census, outside the capture
+    comp.run(d_in)  # warm-up outside the capture
     dec.run(comp.out, comp.capacity)
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
@@ -496,7 +608,7 @@ def test_indexed_path_is_graph_capturable(wah, oracle):
     srcs = [_dev(oracle.gen_uniform(n, 5, 0.02)), _dev(oracle.gen_clustered(n, 6, 900))]
     d_a, d_b = srcs[0].clone(), srcs[1].clone()
     ca, cb = wah.DeviceCompressor(n, indexed=True), wah.DeviceCompressor(n, indexed=True)
-    ca.run(d_a)  # first calls: census, outside the capture
+    ca.run(d_a)  # warm-up outside the capture
     cb.run(d_b)
     seg_ws = torch.empty(int(wah.lib().wah_decompress_segments_workspace_bytes()), dtype=torch.uint8, device="cuda:0")
     back = torch.empty(n + 1, dtype=torch.int32, device="cuda:0")
