@@ -116,6 +116,7 @@ __device__ __forceinline__ void stage_prefetched(const Prefetch &p, u32 *lds, u3
 // never merge, so the last real group closes its run and each of them becomes one entry BEHIND the real ones, which
 // is simply not counted.
 constexpr u32 kAbsentGroup = 0x2AAAAAAAu;
+constexpr u32 kSparseBelow = 192; // words per segment below which pass 2 takes its step-skipping variant
 
 struct SegGroups {
     u32 x[kSteps]; // group 64 s + lane of the segment
@@ -175,7 +176,8 @@ __device__ __forceinline__ bool segment_has_fill(const SegGroups &g, u32 ends, u
     return __ballot(lo == 0u || hi == kOnes31) != 0;
 }
 
-__device__ __forceinline__ void classify_pass2(const SegGroups &g, SegEnds e, u32 *lds, unsigned short *pos, u32 lane_v) {
+// sparse: the segment compressed to few words (pass 1 counted them): most steps lie inside long fills and are skipped
+__device__ __forceinline__ void classify_pass2(const SegGroups &g, SegEnds e, u32 *lds, unsigned short *pos, u32 lane_v, bool sparse) {
     // mask : the step's run ends come back out of the flag word, top bit first (v_add_co f, f, f: the carry is the mask)
     // rank : v_mbcnt pair seeded with the running count (kept in a VECTOR register: no scalar work); count += v_bcnt pair
     // write: every lane stores; lanes that end no run store to a dump slot (cheaper than masking EXEC)
@@ -190,6 +192,21 @@ __device__ __forceinline__ void classify_pass2(const SegGroups &g, SegEnds e, u3
     u32 na, ta, nb, tb, ps;
     const u32 lane2 = lane_v * 0x10001u; // the lane id in both halves: position words are built two at a time
     u32 f = e << 16;                     // step 0 at the top
+    if (sparse) {
+        asm volatile(
+#include "classify_pass2_skip_a.inc"
+            : [f] "+&v"(f), [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)
+            : [x0] "v"(g.x[0]), [x1] "v"(g.x[1]), [x2] "v"(g.x[2]), [x3] "v"(g.x[3]), [x4] "v"(g.x[4]), [x5] "v"(g.x[5]), [x6] "v"(g.x[6]),
+              [x7] "v"(g.x[7]), [ln2] "v"(lane_v), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)
+            : "vcc", "scc", "memory");
+        asm volatile(
+#include "classify_pass2_skip_b.inc"
+            : [f] "+&v"(f), [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)
+            : [x0] "v"(g.x[8]), [x1] "v"(g.x[9]), [x2] "v"(g.x[10]), [x3] "v"(g.x[11]), [x4] "v"(g.x[12]), [x5] "v"(g.x[13]),
+              [x6] "v"(g.x[14]), [x7] "v"(g.x[15]), [ln2] "v"(lane_v), [vb] "s"(vbase), [pb] "s"(pbase), [dm] "v"(dump_slot)
+            : "vcc", "scc", "memory");
+        return;
+    }
     asm volatile(
 #include "classify_pass2_a.inc"
         : [f] "+&v"(f), [na] "=&v"(na), [ta] "=&v"(ta), [nb] "=&v"(nb), [tb] "=&v"(tb), [ps] "=&v"(ps), [cn] "+&v"(count_v)
@@ -460,7 +477,7 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
     for (u32 j = 0; j < kWaveSegs; ++j) {
         if (seg0 + j < a.n_segments) {
             if (lane == 0) pos[0] = 0xFFFFu; // position "-1": the run before the first one ends there
-            classify_pass2(grp[j], ends[j], stage, pos, lane);
+            classify_pass2(grp[j], ends[j], stage, pos, lane, cnt[j] < kSparseBelow);
             const bool any_fill = segment_has_fill(grp[j], cnt[j] + (kSegGroups - nval[j]), nval[j]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             final_words_to_regs(stage, pos, lane, cnt[j], any_fill, out[j]);

@@ -5,6 +5,7 @@
  * Every function cites the reference lines it restates.  Nothing here is
  * derived from the product's HIP code; the two only meet in tests/.
  */
+#define _POSIX_C_SOURCE 200809L /* pthread_barrier_t under -std=c11 */
 #include "wah_oracle.h"
 
 #include <pthread.h>
@@ -105,17 +106,38 @@ uint64_t wah_oracle_compress(const uint32_t *in, uint64_t n_words, uint32_t *out
     return compress_segments(in, n_words, 0, segment_count(n_words), out);
 }
 
-/* ---- multi-threaded variant (CPU baseline only) ---- */
+/* ---- multi-threaded variant (CPU baseline only) ----
+ * Segments are independent (F4): every thread COUNTS the words of its contiguous range of segments (compressing each
+ * segment into a 4 KiB stack buffer), thread 0 turns the per-thread counts into offsets (= the block-offset scan,
+ * compress.cu:146), and every thread compresses its range again, straight to its place.  (Per-thread buffers of up to
+ * a bitmap's worth of words + a serial join made the all-cores figure slower than one core on incompressible data:
+ * page faults on the second copy of the output, not arithmetic, set the pace.) */
 typedef struct {
     const uint32_t *in;
     uint64_t n_words, seg_lo, seg_hi;
-    uint32_t *tmp;
-    uint64_t count;
+    uint32_t *out;
+    uint64_t count, offset;
+    pthread_barrier_t *counted, *placed;
+    void *all;
+    int index, threads;
 } mt_job;
 
 static void *mt_worker(void *p) {
     mt_job *j = (mt_job *)p;
-    j->count = compress_segments(j->in, j->n_words, j->seg_lo, j->seg_hi, j->tmp);
+    uint32_t one[WAH_O_SEG_GROUPS + 1]; /* a segment emits at most 1024 words */
+    j->count = 0;
+    for (uint64_t s = j->seg_lo; s < j->seg_hi; ++s) j->count += compress_segments(j->in, j->n_words, s, s + 1, one);
+    pthread_barrier_wait(j->counted);
+    if (j->index == 0) {
+        mt_job *all = (mt_job *)j->all;
+        uint64_t c = 0;
+        for (int t = 0; t < j->threads; ++t) {
+            all[t].offset = c;
+            c += all[t].count;
+        }
+    }
+    pthread_barrier_wait(j->placed);
+    (void)compress_segments(j->in, j->n_words, j->seg_lo, j->seg_hi, j->out + j->offset);
     return NULL;
 }
 
@@ -126,6 +148,9 @@ uint64_t wah_oracle_compress_mt(const uint32_t *in, uint64_t n_words, uint32_t *
     if (threads == 1) return wah_oracle_compress(in, n_words, out);
     mt_job *jobs = (mt_job *)calloc((size_t)threads, sizeof(mt_job));
     pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    pthread_barrier_t counted, placed;
+    pthread_barrier_init(&counted, NULL, (unsigned)threads);
+    pthread_barrier_init(&placed, NULL, (unsigned)threads);
     const uint64_t per = (nseg + threads - 1) / threads;
     for (int t = 0; t < threads; ++t) {
         uint64_t lo = per * t, hi = lo + per;
@@ -135,17 +160,21 @@ uint64_t wah_oracle_compress_mt(const uint32_t *in, uint64_t n_words, uint32_t *
         jobs[t].n_words = n_words;
         jobs[t].seg_lo = lo;
         jobs[t].seg_hi = hi;
-        /* each segment emits at most 1024 words */
-        jobs[t].tmp = (uint32_t *)malloc((size_t)((hi - lo) * WAH_O_SEG_GROUPS + 1) * sizeof(uint32_t));
+        jobs[t].out = out;
+        jobs[t].counted = &counted;
+        jobs[t].placed = &placed;
+        jobs[t].all = jobs;
+        jobs[t].index = t;
+        jobs[t].threads = threads;
         pthread_create(&tid[t], NULL, mt_worker, &jobs[t]);
     }
     uint64_t c = 0;
     for (int t = 0; t < threads; ++t) {
         pthread_join(tid[t], NULL);
-        memcpy(out + c, jobs[t].tmp, (size_t)jobs[t].count * sizeof(uint32_t)); /* = the block-offset scan, compress.cu:146 */
         c += jobs[t].count;
-        free(jobs[t].tmp);
     }
+    pthread_barrier_destroy(&counted);
+    pthread_barrier_destroy(&placed);
     free(jobs);
     free(tid);
     return c;

@@ -11,6 +11,7 @@
                              f = f + f: the carry IS the mask), then the rank of every run end (v_mbcnt over the mask,
                              seeded with the running count) and the compaction stores: the group's value at its rank,
                              its position beside it.  8.5 vector + 2 LDS instructions per step.
+  classify_pass2_skip_*.inc  the same for segments that compressed to few words: steps without a run end are branched over.
 
 Pass 1 needs nothing but the groups and leaves ONE register per segment behind; the kernel publishes the word counts of
 all its segments right after it and runs pass 2 while the other workgroups' counts are on their way.
@@ -88,8 +89,34 @@ def pass2(half):
     return out
 
 
+def pass2_skip(half):
+    """PASS 2 for a segment that compressed to few words (known from pass 1): a step without a single run end -- the
+    inside of a long fill -- costs one vector and two scalar instructions instead of eleven."""
+    out = []
+    emit = out.append
+    for s in range(HALF):
+        g = half * HALF + s
+        n, t = temps(s)
+        emit("v_add_co_u32 %[f], vcc, %[f], %[f]")  # vcc = the step's run ends
+        emit("s_cmp_eq_u64 vcc, 0")
+        emit(f"s_cbranch_scc1 .Lwah_p2skip_%=_{g}")
+        emit(f"v_mbcnt_lo_u32_b32 %[{n}], vcc_lo, %[cn]")
+        emit(f"v_mbcnt_hi_u32_b32 %[{n}], vcc_hi, %[{n}]")
+        emit("v_bcnt_u32_b32 %[cn], vcc_lo, %[cn]")
+        emit("v_bcnt_u32_b32 %[cn], vcc_hi, %[cn]")
+        emit(f"v_add_u32 %[ps], 0x{64 * g:x}, %[ln2]")  # position 64 g + lane (low half)
+        emit(f"v_cndmask_b32 %[{n}], %[dm], %[{n}], vcc")
+        emit(f"v_lshl_add_u32 %[{t}], %[{n}], 2, %[vb]")
+        emit(f"v_lshl_add_u32 %[{n}], %[{n}], 1, %[pb]")
+        emit(f"ds_write_b32 %[{t}], %[x{s}]")
+        emit(f"ds_write_b16 %[{n}], %[ps]")
+        emit(f".Lwah_p2skip_%=_{g}:")
+    return out
+
+
 here = os.path.dirname(os.path.abspath(__file__))
-for name, lines in (("classify_pass1.inc", pass1()), ("classify_pass2_a.inc", pass2(0)), ("classify_pass2_b.inc", pass2(1))):
+for name, lines in (("classify_pass1.inc", pass1()), ("classify_pass2_a.inc", pass2(0)), ("classify_pass2_b.inc", pass2(1)),
+                    ("classify_pass2_skip_a.inc", pass2_skip(0)), ("classify_pass2_skip_b.inc", pass2_skip(1))):
     with open(os.path.join(here, "..", "gpu-wah_amd", "csrc", name), "w") as f:
         f.write("// GENERATED by tools/gen_classify_block.py -- do not edit (see there for the schedule)\n")
         for line in lines:
