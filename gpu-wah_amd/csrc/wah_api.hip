@@ -783,7 +783,7 @@ int wah_decompress_segments_device(const uint32_t *d_comp, uint64_t c_words, con
     }
     if (workspace_bytes < wah_decompress_segments_workspace_bytes()) {
         set_err("workspace too small");
-        return WAH_ERR_ARG;
+        return WAH_ERR_WORKSPACE;
     }
     const uint64_t groups = wah_max_compressed_words(n_words); // G = ceil(32 n / 31)
     const uint64_t all_segments = (groups + wah::kSegGroups - 1) / wah::kSegGroups;

@@ -23,7 +23,7 @@ for kind in sys.argv[1:] or ["sparse"]:
     comp.status()
     comp.run(d)
     comp.status()
-    n_tiles = (270600 + 15) // 16
+    n_tiles = (270600 + 39) // 40
     t = comp.seg_offsets[: n_tiles * 8].cpu().numpy().reshape(n_tiles, 8).astype(np.int64)
     start, pub, sweep, done, polls = t[:, 0], t[:, 1], t[:, 2], t[:, 3], t[:, 4]
     t0 = start.min()
