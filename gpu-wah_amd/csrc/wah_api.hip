@@ -357,9 +357,9 @@ size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_wo
 static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int op, const wah::PairCheck *check, uint64_t n_words,
                                 uint32_t *d_out, uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_segment_offsets,
                                 void *d_workspace, size_t workspace_bytes, void *stream, bool clear_first,
-                                uint64_t *host_result = nullptr) {
+                                uint64_t *host_result = nullptr, const wah::BitopOperands *indexed = nullptr) {
     g_err[0] = 0;
-    if (!d_out_words || !d_workspace || (n_words && (!d_in || !d_out))) {
+    if (!d_out_words || !d_workspace || (n_words && ((!d_in && !indexed) || !d_out))) {
         set_err("null pointer");
         return WAH_ERR_ARG;
     }
@@ -398,6 +398,10 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     a.n_segments = (uint32_t)l.n_segments;
     a.n_tiles = (uint32_t)l.n_tiles;
     a.wave_segs = l.wave_segs;
+    if (indexed) { // groups come from two indexed streams (bitop_tile_kernel): its own tile shape
+        a.wave_segs = wah::kIndexedSegsPerWave;
+        a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * wah::kIndexedSegsPerWave);
+    }
     a.fast_segments = aligned16(d_in) ? 1u : 0u;
     a.full_segments = (uint32_t)(n_words / wah::kSegWords);
     a.tail_bytes = (uint32_t)(n_words % wah::kSegWords) * 4u;
@@ -427,7 +431,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
         }
         if (check) e = wah::launch_bitop_check(check->info_a, check->info_b, check->ctrl_a, check->ctrl_b, check->groups, a.ctrl, s);
     }
-    if (e == hipSuccess) e = wah::launch_compress(a, s);
+    if (e == hipSuccess) e = indexed ? wah::launch_bitop_tiles(a, *indexed, s) : wah::launch_compress(a, s);
     if (e != hipSuccess) {
         set_err("compress kernel launch", e);
         return WAH_ERR_HIP;
@@ -861,33 +865,26 @@ int wah_bitop_indexed_device(int op, uint64_t n_words, const uint32_t *d_a, uint
         return WAH_ERR_WORKSPACE;
     }
     char *sc = static_cast<char *>(d_scratch);
-    uint32_t *combined = reinterpret_cast<uint32_t *>(sc + l.bitmap);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint64_t groups = wah_max_compressed_words(n_words);
-    hipError_t e = wah::launch_clear(sc, wah::kCtlWords * sizeof(uint32_t), s);
-    if (e == hipSuccess) {
-        wah::BitopSegArgs a = {};
-        a.a.comp = d_a;
-        a.a.c_words = a_words;
-        a.a.seg_offsets = d_a_offsets;
-        a.a.first_segment = 0;
-        a.a.n_segments = (groups + wah::kSegGroups - 1) / wah::kSegGroups;
-        a.a.groups = groups;
-        a.a.out_words = wah_decoded_words(groups);
-        a.a.out = combined;
-        a.a.ctrl = reinterpret_cast<uint32_t *>(sc);
-        a.comp_b = d_b;
-        a.c_words_b = b_words;
-        a.seg_offsets_b = d_b_offsets;
-        a.op = op;
-        e = wah::launch_bitop_segments(a, s);
-    }
+    // ONE kernel: both operands are walked segment by segment through their indexes, combined group by group in
+    // registers, and the combined groups go straight into the compress passes -- no decoded bitmap is written or read
+    // (the scratch's bitmap area stays unused on this route; the many-operand call still goes through it).
+    hipError_t e = wah::launch_clear(sc, wah::kCtlWords * sizeof(uint32_t), s); // (read by wah_bitop_indexed_status)
     if (e != hipSuccess) {
-        set_err("combining pass launch", e);
+        set_err("clearing the scratch", e);
         return WAH_ERR_HIP;
     }
-    return compress_device_impl(combined, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, d_out_offsets,
-                                sc + l.ws_c, l.ws_c_bytes, stream, true);
+    wah::BitopOperands ops;
+    ops.comp_a = d_a;
+    ops.comp_b = d_b;
+    ops.c_words_a = a_words;
+    ops.c_words_b = b_words;
+    ops.offs_a = d_a_offsets;
+    ops.offs_b = d_b_offsets;
+    ops.groups = wah_max_compressed_words(n_words);
+    ops.op = (uint32_t)op;
+    return compress_device_impl(nullptr, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, d_out_offsets,
+                                sc + l.ws_c, l.ws_c_bytes, stream, true, nullptr, &ops);
 }
 
 int wah_bitop_many_indexed_device(int op, uint64_t n_words, int n_operands, const uint32_t *const *d_streams,

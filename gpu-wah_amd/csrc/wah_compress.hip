@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 #include "wah_device.hpp"
+#include "wah_segdecode.hpp"
 
 namespace wah {
 namespace {
@@ -44,6 +45,7 @@ namespace {
 constexpr u32 kStageWords = 1024; // staged segment (992 words + look-ahead) / compacted output words (<= 1024), aliased
 constexpr u32 kOutWords = kStageWords + 4; // + one dump dword (non-end lanes), kept 16-byte aligned
 constexpr u32 kPosEntries = 1032; // pos[0] = -1 sentinel, pos[k+1] = group position of run end k (u16)
+static_assert(kPosEntries * 2 % 16 == 0 && kPosEntries * 2 >= kSegGroups, "the position array doubles as the segment decoder's flag area");
 
 struct Prefetch {
     u32x4 v[4];
@@ -361,13 +363,112 @@ __device__ __forceinline__ void emit_regs(const CompressArgs &a, u64 base, u32 c
     }
 }
 
+// Where a wave's 31-bit groups come from -- the only thing that differs between compressing a bitmap and combining
+// compressed bitmaps: a SOURCE leaves the groups of one segment in registers (SegGroups) and keeps the next segment's
+// loads in flight meanwhile.
+//   BitmapSource  : the bitmap itself (wah_compress_device; kPair: two decoded bitmaps combined word by word, wah_bitop_device)
+//   IndexedSource : the same segment of TWO indexed compressed streams, expanded and combined group by group
+//                   (wah_bitop_indexed_device) -- the result is compressed without ever existing as a bitmap
+template <bool kPair, bool kAligned>
+struct BitmapSource {
+    Prefetch pre, pre2; // pre2: pair mode only, the second bitmap's words
+    __device__ __forceinline__ void begin(const CompressArgs &a, u32 seg0, u32, u32 lane) {
+        if (seg0 < a.n_segments) {
+            prefetch_segment<kAligned>(a.in, a, seg0, lane, pre);
+            if (kPair) prefetch_segment<kAligned>(a.in2, a, seg0, lane, pre2);
+        }
+    }
+    // segment `seg` -> g; `more`: the wave has another segment after this one
+    __device__ __forceinline__ void produce(const CompressArgs &a, u32 seg, bool more, u32 nvalid, u32 *stage, unsigned short *, u32 lane,
+                                            SegGroups &g) {
+        if (kPair) combine_pair(pre, pre2, a.op);
+        stage_prefetched(pre, stage, lane);
+        // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // the next segment's loads are in flight while this one is classified
+        if (more && seg + 1 < a.n_segments) {
+            prefetch_segment<kAligned>(a.in, a, seg + 1, lane, pre);
+            if (kPair) prefetch_segment<kAligned>(a.in2, a, seg + 1, lane, pre2);
+        }
+        regroup(stage + ((31u * lane) >> 5), (31u * lane) & 31u, lane, nvalid, g);
+    }
+};
+
+// The wave's LDS buffer doubles as the segment decoder's areas (wah_segdecode.hpp): 4 KiB of words, 1 KiB of flags.
+struct IndexedSource {
+    SegmentsArgs sa, sb;         // geometry + stream of operand A / B
+    const u64 *offs_a, *offs_b;  // their segment indexes
+    u32 op;
+    u64 oa, ob;                  // lane j: first word of segment seg0 + j in A / B (one load per operand for the whole wave)
+    u32 x0[kSegBatches], x1[kSegBatches], y0[kSegBatches], y1[kSegBatches];
+    SegRange ra, rb;
+    bool bad = false;
+
+    __device__ __forceinline__ void load(const CompressArgs &a, u32 j, u32 lane) {
+        ra = seg_range(sa, 0, uniform64(__shfl(oa, (int)j)), uniform64(__shfl(oa, (int)j + 1)));
+        rb = seg_range(sb, 0, uniform64(__shfl(ob, (int)j)), uniform64(__shfl(ob, (int)j + 1)));
+        (void)a;
+        seg_load_words(sa, ra, x0, x1, lane);
+        seg_load_words(sb, rb, y0, y1, lane);
+    }
+    __device__ __forceinline__ void begin(const CompressArgs &a, u32 seg0, u32 n_segs, u32 lane) {
+        // the index entries of all the wave's segments (and the one behind them) in one round trip
+        const u64 i = (u64)seg0 + lane;
+        const bool in = lane <= n_segs && i <= a.n_segments;
+        oa = in ? offs_a[i] : 0;
+        ob = in ? offs_b[i] : 0;
+        if (seg0 < a.n_segments) load(a, 0, lane);
+    }
+    __device__ __forceinline__ void produce(const CompressArgs &a, u32 seg, bool more, u32 nvalid, u32 *stage, unsigned short *pos, u32 lane,
+                                            SegGroups &g) {
+        unsigned char *flag = reinterpret_cast<unsigned char *>(pos);
+        ra.nvalid = rb.nvalid = nvalid;
+        bool ok = seg_mark(ra, x0, x1, flag, stage, lane);
+        u32 ga[kSteps];
+        {
+            const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
+            const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
+            u32 before = 0xFFFFFFFFu;
+#pragma unroll
+            for (int s = 0; s < (int)kSteps; ++s) ga[s] = seg_group(s, f, before, stage, ok ? ra.cnt : 1u, nvalid, lane);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // A's words and flags have been read: the areas go to B
+        ok = seg_mark(rb, y0, y1, flag, stage, lane) && ok;
+        const u32 cnt_b = ok ? rb.cnt : 1u;
+        // the next segment's words are in flight while this one is expanded and classified
+        const u32 j = seg - (seg / kIndexedSegsPerWave) * kIndexedSegsPerWave; // position inside the wave's run of segments
+        if (more && seg + 1 < a.n_segments) load(a, j + 1, lane);
+        bad |= !ok;
+        // any of the four operations (include/wah.h: WAH_OP_AND 0, OR 1, XOR 2, ANDNOT 3) as a sum of minterms; the
+        // masks are wave-uniform
+        const u32 k_ab = op <= 1 ? ~0u : 0u;
+        const u32 k_a_nb = op == 0 ? 0u : ~0u;
+        const u32 k_na_b = op == 1 || op == 2 ? ~0u : 0u;
+        const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
+        const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
+        u32 before = 0xFFFFFFFFu;
+#pragma unroll
+        for (int s = 0; s < (int)kSteps; ++s) {
+            const u32 gb = seg_group(s, f, before, stage, cnt_b, nvalid, lane);
+            g.x[s] = ((ga[s] & gb & k_ab) | (ga[s] & ~gb & k_a_nb) | (~ga[s] & gb & k_na_b)) & kOnes31;
+        }
+        if (nvalid != kSegGroups) { // the bitmap's last, short segment: absent groups become throw-away literals (regroup())
+            u32 lv = lane;
+            asm volatile("" : "+v"(lv));
+#pragma unroll
+            for (int s = 0; s < (int)kSteps; ++s) g.x[s] = 64u * s + lv < nvalid ? g.x[s] : kAbsentGroup;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the areas are written again by pass 2 / the next segment
+    }
+};
+
 // kWaveSegs: segments a wavefront compresses one after the other (the tile = kTileWaves x kWaveSegs segments).  Large
 // bitmaps take 5: a wave's four idle stretches (first load, barrier, offset, store drain) are paid once per five
 // segments, and 16 waves per CU keep 80 segments in flight.  Small bitmaps take 1 or 2: more, shorter tiles.
-template <bool kPair, bool kAligned, u32 kWaveSegs>
-__global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compress_tile_kernel(const CompressArgs a) {
+template <class Source, u32 kWaveSegs>
+__device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source &src) {
     __shared__ __attribute__((aligned(16))) u32 s_out[kTileWaves][kOutWords];
-    __shared__ unsigned short s_pos[kTileWaves][kPosEntries];
+    __shared__ __attribute__((aligned(16))) unsigned short s_pos[kTileWaves][kPosEntries];
     __shared__ u32 s_count[kTileWaves];
     __shared__ u32 s_prefix[kTileWaves];
     __shared__ u64 s_base;
@@ -399,8 +500,6 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
     //      second LDS pass, and twice as many segments are in flight per CU as there are LDS buffers -------------------
     u32 *const stage = s_out[wave];
     unsigned short *const pos = s_pos[wave];
-    const u32 r = (31u * lane) & 31u;
-    const u32 *const sp = stage + ((31u * lane) >> 5);
     u32 out[kWaveSegs][16];
     u32 cnt[kWaveSegs];
     SegGroups grp[kWaveSegs];
@@ -408,33 +507,18 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
     u32 nval[kWaveSegs];
     u32 never;
     asm volatile("v_mov_b32 %0, -1" : "=v"(never)); // "group after the last one": a value no 31-bit group can equal
-    Prefetch pre, pre2; // pre2: pair mode only (wah_bitop_device), the second bitmap's words
-    if (seg0 < a.n_segments) {
-        prefetch_segment<kAligned>(a.in, a, seg0, lane, pre);
-        if (kPair) prefetch_segment<kAligned>(a.in2, a, seg0, lane, pre2);
-    }
-    // ---- pass 1 of both segments: nothing but their word counts, which is all the other workgroups wait for.  Every
-    //      tile behind this one waits for that count, so this part runs at raised priority; what follows the publication
-    //      (pass 2, final words) has the round trip of the sweep to hide in and runs at the lowest ------------------------
-    if ((a.tune & 3u) != 1u) __builtin_amdgcn_s_setprio(3);
+    src.begin(a, seg0, kWaveSegs, lane);
+    // ---- pass 1 of all the wave's segments: nothing but their word counts, which is all the other workgroups wait for.
+    //      What follows the publication (pass 2, final words) has the round trip of the sweep to hide in ----------------
 #pragma unroll
     for (u32 j = 0; j < kWaveSegs; ++j) {
         const u32 seg = seg0 + j;
         cnt[j] = 0;
         nval[j] = kSegGroups;
         if (seg < a.n_segments) {
-            if (kPair) combine_pair(pre, pre2, a.op);
-            stage_prefetched(pre, stage, lane);
-            // the wave re-reads other lanes' words: order the LDS traffic at wavefront scope (no barrier needed)
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            if (j == 0) DG(1);
-            // the next segment's loads are in flight while this one is classified
-            if (j + 1 < kWaveSegs && seg + 1 < a.n_segments) {
-                prefetch_segment<kAligned>(a.in, a, seg + 1, lane, pre);
-                if (kPair) prefetch_segment<kAligned>(a.in2, a, seg + 1, lane, pre2);
-            }
             nval[j] = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
-            regroup(sp, r, lane, nval[j], grp[j]);
+            src.produce(a, seg, j + 1 < kWaveSegs, nval[j], stage, pos, lane, grp[j]);
+            if (j == 0) DG(1);
             cnt[j] = classify_pass1(grp[j], never, ends[j]) - (kSegGroups - nval[j]);
         }
     }
@@ -445,7 +529,6 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
     DG(2);
     __syncthreads();
     DG(3);
-    if ((a.tune & 3u) != 1u && wave != 0) __builtin_amdgcn_s_setprio(0);
 
     // ---- wave 0: the tile's count goes out, the sweep of the others' counts is issued --------------------------------
     const ScanGeom g = scan_geom(tile);
@@ -463,7 +546,6 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
         // One round trip of three loads per lane, issued now that the count is out and collected after pass 2: by
         // then the tiles dispatched before this one have normally published theirs.
         scan_issue(a, g, lane, true, g.has_prev, true, poll);
-        if ((a.tune & 3u) != 1u) __builtin_amdgcn_s_setprio(0);
 #ifdef WAH_DIAG
         if (a.tune == 77u) { // time line mode: how long does the sweep itself take?
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -649,6 +731,32 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
     }
 }
 
+template <bool kPair, bool kAligned, u32 kWaveSegs>
+__global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compress_tile_kernel(const CompressArgs a) {
+    BitmapSource<kPair, kAligned> src;
+    compress_tile_body<BitmapSource<kPair, kAligned>, kWaveSegs>(a, src);
+}
+
+// wah_bitop_indexed_device: compress(A op B) straight from the two indexed streams.  Same tile kernel; the groups come
+// from the segment decoder instead of the bitmap.  Nothing of bitmap size is written or read: traffic = 4 C_A + 4 C_B
+// + 4 C_out (+ the indexes).  A range that is not exactly its segment (not a stream of compress() for this bitmap) is
+// reported as WAH_ERR_STREAM; the output is then undefined but every access stays inside the buffers.
+__global__ __launch_bounds__(kTileWaves * 64, 4) void bitop_tile_kernel(const CompressArgs a, const BitopOperands ops) {
+    IndexedSource src;
+    src.sa = SegmentsArgs{};
+    src.sa.comp = ops.comp_a;
+    src.sa.c_words = ops.c_words_a;
+    src.sa.groups = ops.groups;
+    src.sb = src.sa;
+    src.sb.comp = ops.comp_b;
+    src.sb.c_words = ops.c_words_b;
+    src.offs_a = ops.offs_a;
+    src.offs_b = ops.offs_b;
+    src.op = ops.op;
+    compress_tile_body<IndexedSource, kIndexedSegsPerWave>(a, src);
+    if (__any(src.bad) && lane_id() == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+}
+
 } // namespace
 
 template <bool kPair, bool kAligned>
@@ -668,6 +776,11 @@ hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {
         launch_tiles<false, true>(a, s);
     else // input only 4-byte aligned: dword loads
         launch_tiles<false, false>(a, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_bitop_tiles(const CompressArgs &a, const BitopOperands &ops, hipStream_t s) {
+    hipLaunchKernelGGL(bitop_tile_kernel, dim3(a.n_tiles), dim3(kTileWaves * 64), 0, s, a, ops);
     return hipGetLastError();
 }
 

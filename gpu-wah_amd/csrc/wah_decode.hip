@@ -1,6 +1,7 @@
 // wah_decode.hip -- decompress: decode_sums_kernel (tile bases) and decode_expand_kernel (see wah_compress.hip for the
 // conventions; the shared wavefront helpers are in wah_device.hpp)
 #include "wah_device.hpp"
+#include "wah_segdecode.hpp"
 
 namespace wah {
 namespace {
@@ -639,88 +640,6 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
 #endif
 constexpr int kSegDecodeWaves = WAH_SEG_WAVES;
 
-constexpr int kSegBatches = kSegGroups / 128;
-
-// where segment `seg` of the bitmap lies in the stream
-struct SegRange {
-    u64 w0;
-    u32 cnt, nvalid;
-    bool bad;
-};
-__device__ __forceinline__ SegRange seg_range(const SegmentsArgs &a, u64 seg, u64 w0, u64 w1) {
-    SegRange r;
-    const u64 g0 = seg * kSegGroups;
-    r.nvalid = a.groups - g0 < kSegGroups ? (u32)(a.groups - g0) : kSegGroups;
-    // every word of a compress() stream covers at least one group
-    r.bad = w1 < w0 || w1 > a.c_words || w1 - w0 > r.nvalid;
-    r.cnt = r.bad ? 0u : (u32)(w1 - w0);
-    r.w0 = w0;
-    return r;
-}
-// the segment's words: 128 per batch, two per lane (reads past the range return 0)
-__device__ __forceinline__ void seg_load_words(const SegmentsArgs &a, const SegRange &r, u32 (&x0)[kSegBatches], u32 (&x1)[kSegBatches], u32 lane) {
-    const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(a.comp + r.w0, r.cnt * 4u);
-#pragma unroll
-    for (int b = 0; b < kSegBatches; ++b) {
-        x0[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u, 0, 0);
-        x1[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u + 4u, 0, 0);
-    }
-}
-
-// Mark phase of one segment: parks its words (x0/x1, two per lane and batch) in `words` and flags the group at which
-// every word starts (as mark_pairs).  Returns false when the range is not exactly this segment: the words must add up
-// to nvalid groups, none of them empty -- then the r-th flag is the r-th word.
-__device__ __forceinline__ bool seg_mark(const SegRange &rg, const u32 (&x0)[kSegBatches], const u32 (&x1)[kSegBatches],
-                                         unsigned char *flag, u32 *words, u32 lane) {
-    const u32 cnt = rg.cnt, nvalid = rg.nvalid;
-    reinterpret_cast<uint4 *>(flag)[lane] = make_uint4(0, 0, 0, 0); // 64 lanes x 16 B = the 1024 flags
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const u32 fbase = (u32)(uintptr_t)(lds_u8_ptr)flag;
-    const u32 wbase = (u32)(uintptr_t)(lds_u8_ptr)reinterpret_cast<unsigned char *>(words);
-    u32 pos = 0; // groups covered by the batches so far
-    bool empty_word = false;
-#pragma unroll
-    for (int b = 0; b < kSegBatches; ++b) {
-        const u32 wi = 128u * b;
-        if (wi < cnt) { // wave-uniform
-            // a lane without a word stores its flag byte into its own word slot instead, which is past the segment's
-            // words and never read (no dump area: 20 KiB of LDS per workgroup, eight workgroups per CU)
-            const u32 dump = wbase + (wi + 2u * lane) * 4u;
-            const u32 i0 = wi + 2u * lane;
-            const bool in0 = i0 < cnt, in1 = i0 + 1u < cnt;
-            reinterpret_cast<uint2 *>(words)[64 * b + (int)lane] = make_uint2(x0[b], x1[b]);
-            // counts are clamped so that a corrupt word cannot wrap the 32-bit sums; anything above 1024 fails the total
-            const u32 n0 = in0 ? min(word_groups(x0[b]), 2u * kSegGroups) : 0u, n1 = in1 ? min(word_groups(x1[b]), 2u * kSegGroups) : 0u;
-            empty_word |= (in0 && n0 == 0u) || (in1 && n1 == 0u);
-            // a full batch of literals (dense data): consecutive positions, no scan
-            const u32 incl = (wi + 128u <= cnt && __ballot((int)(x0[b] | x1[b]) < 0) == 0) ? 2u * lane + 2u : wave_scan_incl32(n0 + n1);
-            const u32 lo1 = pos + incl - n1, lo0 = lo1 - n0;
-            const bool c0 = in0 && lo0 < nvalid, c1 = in1 && lo1 < nvalid;
-            const u32 a0 = (u32)__mul24((int)(lo0 >> 6), -1023) + ((lo0 << 4) + fbase); // flag_slot(lo0), three instructions
-            const u32 a1 = (u32)__mul24((int)(lo1 >> 6), -1023) + ((lo1 << 4) + fbase);
-            *(lds_u8_ptr)(uintptr_t)(c0 ? a0 : dump) = 1;
-            *(lds_u8_ptr)(uintptr_t)(c1 ? a1 : dump + 4u) = 1;
-            pos += (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    return !(rg.bad || pos != nvalid || __ballot(empty_word) != 0);
-}
-
-// Step s of the expansion (expand_steps()): the 31-bit group 64 s + lane of a marked segment.  f: the lane's 16 flag
-// bytes; before: flags in earlier steps - 1 (carried from step to step).
-__device__ __forceinline__ u32 seg_group(int s, const u32 (&f)[4], u32 &before, const u32 *words, u32 cnt, u32 nvalid, u32 lane) {
-    const u32 fb = (f[s >> 2] >> (8 * (s & 3))) & 0xFFu;
-    const u64 m = __ballot(fb != 0u);
-    const u32 r = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, fb)) + before;
-    before = (u32)__builtin_amdgcn_readlane((int)r, 63);
-    const u32 src_word = words[min(r, cnt - 1u)];
-    const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
-    u32 grp = (int)src_word < 0 ? fill_val : src_word;
-    if ((u32)(64 * s) + lane >= nvalid) grp = 0u;
-    return grp;
-}
-
 // where the 992 words of segment first_segment + k go, and the lane constants of the 31 -> 32 repack
 struct SegStore {
     __amdgpu_buffer_rsrc_t rsrc;
@@ -772,59 +691,6 @@ __global__ __launch_bounds__(kSegDecodeWaves * 64) void decode_segments_kernel(c
     u32 x0[kSegBatches], x1[kSegBatches];
     seg_load_words(a, rg, x0, x1, lane);
     seg_expand(a, k, rg, x0, x1, s_flag[wave], s_seg[wave], lane);
-}
-
-// wah_bitop_indexed_device: the same segment of TWO indexed streams, combined group by group, written as decoded words.
-// Operand A is expanded into 16 registers, the LDS areas are then reused for operand B, whose groups are combined
-// with A's as they come out: still 20 KiB of LDS per workgroup, one pass over both streams, ONE decoded bitmap written
-// (the general route, wah_bitop_device, writes two and reads them back).
-__global__ __launch_bounds__(kSegDecodeWaves * 64) void bitop_segments_kernel(const BitopSegArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kSegDecodeWaves][kSegGroups];
-    __shared__ __attribute__((aligned(16))) u32 s_seg[kSegDecodeWaves][kSegGroups];
-    const u32 wave = wave_id(), lane = lane_id();
-    const u64 k = (u64)blockIdx.x * kSegDecodeWaves + wave;
-    if (k >= a.a.n_segments) return;
-    const u64 seg = a.a.first_segment + k;
-    SegmentsArgs sb = a.a; // operand B: same bitmap geometry, its own stream and index
-    sb.comp = a.comp_b;
-    sb.c_words = a.c_words_b;
-    const SegRange ra = seg_range(a.a, seg, uniform64(a.a.seg_offsets[seg]), uniform64(a.a.seg_offsets[seg + 1]));
-    const SegRange rb = seg_range(sb, seg, uniform64(a.seg_offsets_b[seg]), uniform64(a.seg_offsets_b[seg + 1]));
-    u32 x0[kSegBatches], x1[kSegBatches], y0[kSegBatches], y1[kSegBatches];
-    seg_load_words(a.a, ra, x0, x1, lane);
-    seg_load_words(sb, rb, y0, y1, lane);
-    unsigned char *flag = s_flag[wave];
-    u32 *words = s_seg[wave];
-
-    bool ok = seg_mark(ra, x0, x1, flag, words, lane);
-    u32 ga[kSteps];
-    {
-        const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
-        const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
-        u32 before = 0xFFFFFFFFu;
-#pragma unroll
-        for (int s = 0; s < (int)kSteps; ++s) ga[s] = seg_group(s, f, before, words, ok ? ra.cnt : 1u, ra.nvalid, lane);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // A's words and flags have been read: the areas go to B
-    ok = seg_mark(rb, y0, y1, flag, words, lane) && ok;
-    if (!ok) {
-        if (lane == 0) atomicOr(a.a.ctrl + kCtlError, kErrStream);
-        return;
-    }
-    // any of the four operations (include/wah.h: WAH_OP_AND 0, OR 1, XOR 2, ANDNOT 3) as a sum of minterms; the masks
-    // are wave-uniform
-    const u32 k_ab = a.op <= 1 ? ~0u : 0u;
-    const u32 k_a_nb = a.op == 0 ? 0u : ~0u;
-    const u32 k_na_b = a.op == 1 || a.op == 2 ? ~0u : 0u;
-    const SegStore st = seg_store_setup(a.a.out, a.a.out_words, seg, k, lane);
-    const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
-    const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
-    u32 before = 0xFFFFFFFFu;
-#pragma unroll
-    for (int s = 0; s < (int)kSteps; ++s) {
-        const u32 gb = seg_group(s, f, before, words, rb.cnt, rb.nvalid, lane);
-        seg_store(st, s, (ga[s] & gb & k_ab) | (ga[s] & ~gb & k_a_nb) | (~ga[s] & gb & k_na_b));
-    }
 }
 
 // wah_bitop_many_indexed_device: up to kMaxBitopOperands indexed streams, combined left to right (A op B op C ...;
@@ -931,13 +797,6 @@ hipError_t launch_decode_segments(const SegmentsArgs &a, hipStream_t s) {
     if (a.n_segments == 0) return hipSuccess;
     const u64 grid = (a.n_segments + kSegDecodeWaves - 1) / kSegDecodeWaves;
     hipLaunchKernelGGL(decode_segments_kernel, dim3((unsigned)grid), dim3(kSegDecodeWaves * 64), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_bitop_segments(const BitopSegArgs &a, hipStream_t s) {
-    if (a.a.n_segments == 0) return hipSuccess;
-    const u64 grid = (a.a.n_segments + kSegDecodeWaves - 1) / kSegDecodeWaves;
-    hipLaunchKernelGGL(bitop_segments_kernel, dim3((unsigned)grid), dim3(kSegDecodeWaves * 64), 0, s, a);
     return hipGetLastError();
 }
 

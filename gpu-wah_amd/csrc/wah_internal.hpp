@@ -125,14 +125,16 @@ struct SegmentsArgs {
     uint32_t *ctrl;
 };
 
-// wah_bitop_indexed_device: operand A as SegmentsArgs (its `out` receives the combined decoded words), operand B beside it
-struct BitopSegArgs {
-    SegmentsArgs a;
-    const uint32_t *comp_b;
-    uint64_t c_words_b;
-    const uint64_t *seg_offsets_b;
-    int op; // WAH_OP_*
+// wah_bitop_indexed_device (fused route): the two indexed operands of bitop_tile_kernel
+constexpr uint32_t kIndexedSegsPerWave = 2; // segments a wavefront of bitop_tile_kernel handles one after the other
+struct BitopOperands {
+    const uint32_t *comp_a, *comp_b;
+    uint64_t c_words_a, c_words_b;
+    const uint64_t *offs_a, *offs_b;
+    uint64_t groups; // G of the bitmap both describe
+    uint32_t op;     // WAH_OP_*
 };
+hipError_t launch_bitop_tiles(const struct CompressArgs &a, const BitopOperands &ops, hipStream_t s);
 
 // wah_bitop_many_indexed_device: g = geometry, output and control block (its comp / seg_offsets are not used)
 constexpr int kMaxBitopOperands = 8;
@@ -162,7 +164,6 @@ hipError_t launch_clear(void *p, size_t bytes, hipStream_t s);
 hipError_t launch_build_index(const uint32_t *comp, uint64_t c_words, const uint64_t *tile_base, const uint64_t *info, uint64_t *offsets,
                               uint64_t capacity, uint32_t *ctrl, uint64_t n_tiles, hipStream_t s);
 hipError_t launch_decode_segments(const SegmentsArgs &a, hipStream_t s);
-hipError_t launch_bitop_segments(const BitopSegArgs &a, hipStream_t s);
 hipError_t launch_bitop_many_segments(const BitopManyArgs &a, hipStream_t s);
 
 // wah_merge_fills_device (after the sums pass): kept-word counts per tile, their scan, scatter, count fix-up
