@@ -267,7 +267,7 @@ static_assert(kRowSlots == kSuperRows + 1, "slot layout");
 static_assert(kSlotShift - 32 == kCountBits, "the high half of a slot carries its epoch where a granule does");
 static_assert(kScanBlockWords >= kSuperRows * kRowTiles + 2 * kRowSlots && kScanSlotsAt == kSuperRows * kRowTiles, "scan block layout");
 
-constexpr u32 kDirectLanes = 6; // up to this many lanes with missing entries are simply read again
+constexpr u32 kDirectLanes = 16; // up to this many lanes with missing entries (the nearest ~64 predecessors) are simply read again
 
 struct TileScan {
     u32x4 a, b; // granules of my row (entries below me; the descriptor cuts the rest off) and of the previous row
@@ -479,7 +479,7 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
     const u32 tile = draw_tile(a.ctrl, &s_tile);
     const u32 seg0 = (tile * kTileWaves + wave) * kWaveSegs; // this wave's segments: seg0 .. seg0 + kWaveSegs - 1
 #ifdef WAH_DIAG
-    u64 dg_t[6];
+    u64 dg_t[8];
     u32 dg_polls = 0;
     dg_t[0] = __builtin_amdgcn_s_memrealtime();
 #define DG(i) dg_t[i] = __builtin_amdgcn_s_memrealtime()
@@ -568,6 +568,7 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
         }
     }
 
+    DG(6);
     if (wave == 0) {
         // ---- the tile's offset ---------------------------------------------------------------------------------------
         // If a few entries of the sweep are still missing (the nearest predecessors), only their lanes read again.  If
@@ -689,12 +690,14 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
     }
     __syncthreads();
 #ifdef WAH_DIAG
-    if (wave == 0 && lane == 0 && a.seg_offsets && a.tune == 77u) { // per-tile time line (tools/tile_timeline.py)
+    if (wave == 0 && lane == 0 && a.seg_offsets && (a.tune == 77u || a.tune == 78u)) { // per-tile time line (tools/tile_timeline.py)
         a.seg_offsets[(u64)tile * 8 + 0] = dg_t[0]; // start
         a.seg_offsets[(u64)tile * 8 + 1] = dg_t[3]; // counts known (barrier 1 passed) = publish
         a.seg_offsets[(u64)tile * 8 + 2] = dg_t[5]; // first sweep returned
         a.seg_offsets[(u64)tile * 8 + 3] = dg_t[4]; // offset known
         a.seg_offsets[(u64)tile * 8 + 4] = dg_polls;
+        a.seg_offsets[(u64)tile * 8 + 5] = dg_t[6]; // pass 2 + final words done
+        a.seg_offsets[(u64)tile * 8 + 6] = __builtin_amdgcn_s_memrealtime(); // barrier 2 passed
     }
     if (wave == 0 && lane == 0 && tile % 67u == 0u) { // a sample: the atomics must not become the bottleneck
         unsigned long long *d = reinterpret_cast<unsigned long long *>(a.ctrl + 192);
@@ -716,7 +719,7 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
 #endif
 
 #ifdef WAH_DIAG
-    if (a.seg_offsets && a.tune == 77u) return; // time line mode: the index buffer holds the stamps
+    if (a.seg_offsets && (a.tune == 77u || a.tune == 78u)) return; // time line mode: the index buffer holds the stamps
 #endif
     // ---- the parked words to their place ---------------------------------------------------------------------------
     u64 base = uniform64(s_base) + uniform32(s_prefix[wave]);
@@ -790,7 +793,7 @@ uint32_t compress_wave_segs(uint64_t n_segments) {
         const char *e = std::getenv("WAH_WAVE_SEGS");
         return e ? std::atoi(e) : 0;
     }();
-    if (forced == 1 || forced == 2 || forced == kCompressMaxWaveSegs) return (uint32_t)forced;
+    if (forced == 1 || forced == 2 || forced == 4 || forced == kCompressMaxWaveSegs) return (uint32_t)forced;
     // measured on 4 MiB .. 512 MiB bitmaps (tools/scratch/size_s_sweep.py): 4 MiB 8.0 / 8.6 / 12.9 us with 1 / 2 / 5
     // segments per wave, 16 MiB 16.2 / 13.1 / 15.0, 32 MiB 27.5 / 21.9 / 17.8, 128 MiB 76.6 / 57.2 / 50.6
     if (n_segments <= 2400) return 1;

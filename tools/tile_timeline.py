@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["WAH_LIB_PATH"] = os.path.join(ROOT, "gpu-wah_amd", "libwah_hip_diag.so")
-os.environ["WAH_TUNE"] = "77"
+os.environ.setdefault("WAH_TUNE", "78")  # 77: wave 0 waits for its first sweep right away (its round trip); 78: normal flow
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -25,12 +25,14 @@ for kind in sys.argv[1:] or ["sparse"]:
     comp.status()
     n_tiles = (270600 + 39) // 40
     t = comp.seg_offsets[: n_tiles * 8].cpu().numpy().reshape(n_tiles, 8).astype(np.int64)
-    start, pub, sweep, done, polls = t[:, 0], t[:, 1], t[:, 2], t[:, 3], t[:, 4]
+    start, pub, sweep, done, polls, p2, bar2 = t[:, 0], t[:, 1], t[:, 2], t[:, 3], t[:, 4], t[:, 5], t[:, 6]
     t0 = start.min()
     us = lambda x: x / 100.0
     print(f"--- {kind}: {n_tiles} tiles, span {us(done.max() - t0):.1f} us")
     print(f"   start->publish {us((pub - start).mean()):.2f} us (p10 {us(np.percentile(pub - start, 10)):.2f}, p90 {us(np.percentile(pub - start, 90)):.2f})")
-    print(f"   sweep round trip {us((sweep - pub).mean()):.2f} us (p10 {us(np.percentile(sweep - pub, 10)):.2f}, p90 {us(np.percentile(sweep - pub, 90)):.2f})")
+    if os.environ["WAH_TUNE"] == "77":
+        print(f"   sweep round trip {us((sweep - pub).mean()):.2f} us (p10 {us(np.percentile(sweep - pub, 10)):.2f}, p90 {us(np.percentile(sweep - pub, 90)):.2f})")
+    print(f"   publish->pass 2 + final words done {us((p2 - pub).mean()):.2f} us; ->offset known {us((done - pub).mean()):.2f}; ->barrier 2 passed {us((bar2 - pub).mean()):.2f}")
     print(f"   publish->offset {us((done - pub).mean()):.2f} us (p50 {us(np.percentile(done - pub, 50)):.2f}, p90 {us(np.percentile(done - pub, 90)):.2f}); re-polls {polls.mean():.2f}")
     # start order: how much later than tile t did the latest-starting lower tile (within 512) start?
     lag_start = np.zeros(n_tiles)
