@@ -38,6 +38,7 @@ ABI_SYMBOLS = {
     "wah_decompress_workspace_bytes": (_sz, [_u64, _u64]),
     "wah_workspace_init_device": (_int, [_vp, _sz, _vp]),
     "wah_compress_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_compress_device_ex": (_int, [_vp, _u64, _vp, _u64, _vp, ctypes.c_uint, _vp, _sz, _vp]),
     "wah_compress_device_indexed": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _sz, _vp]),
     "wah_compress_status": (_int, [_vp, _vp]),
     "wah_decompress_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
@@ -205,8 +206,11 @@ class DeviceCompressor:
     allocated inside run(), so it can be timed (and graph-captured) as pure device work.
     """
 
-    def __init__(self, n_words, device="cuda:0", indexed=False):
+    def __init__(self, n_words, device="cuda:0", indexed=False, unsegmented=False):
         torch = _torch()
+        if indexed and unsegmented:
+            raise WahError("an unsegmented stream has no segment index")
+        self.unsegmented = bool(unsegmented)
         self.n_words = int(n_words)
         self.capacity = max_compressed_words(self.n_words)
         self.ws_bytes = int(lib().wah_compress_workspace_bytes(self.n_words))
@@ -225,7 +229,10 @@ class DeviceCompressor:
         if n > self.n_words or n > d_in.numel():
             raise WahError("input larger than this compressor was sized for")
         sp = _stream_ptr(torch, stream)
-        if self.seg_offsets is None:
+        if self.unsegmented:
+            rc = lib().wah_compress_device_ex(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, self.count.data_ptr(), 1,
+                                              self.workspace.data_ptr(), self.ws_bytes, sp)
+        elif self.seg_offsets is None:
             rc = lib().wah_compress_device(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, self.count.data_ptr(),
                                            self.workspace.data_ptr(), self.ws_bytes, sp)
         else:

@@ -39,7 +39,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 struct CompressLayout {
     uint64_t n_groups, n_segments, n_tiles;
     uint32_t wave_segs;
-    size_t ctrl_off, desc_off, total;
+    size_t ctrl_off, desc_off, unseg_off, total;
 };
 
 // [control block][scan area: one block of kScanBlockWords per 64 x 256 tiles, + the block a full last superrow publishes into]
@@ -53,7 +53,8 @@ CompressLayout compress_layout(uint64_t n_words) {
     const uint64_t blocks = ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves) / wah::kScanBlockTiles + 1;
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
-    l.total = round256(l.desc_off + blocks * wah::kScanBlockWords * sizeof(uint32_t));
+    l.unseg_off = round256(l.desc_off + blocks * wah::kScanBlockWords * sizeof(uint32_t)); // scan area of the unsegmented mode
+    l.total = round256(l.unseg_off + blocks * wah::kUnsegBlockWords * sizeof(uint32_t));
     return l;
 }
 
@@ -357,7 +358,7 @@ size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_wo
 static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int op, const wah::PairCheck *check, uint64_t n_words,
                                 uint32_t *d_out, uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_segment_offsets,
                                 void *d_workspace, size_t workspace_bytes, void *stream, bool clear_first,
-                                uint64_t *host_result = nullptr, const wah::BitopOperands *indexed = nullptr) {
+                                uint64_t *host_result = nullptr, const wah::BitopOperands *indexed = nullptr, bool unsegmented = false) {
     g_err[0] = 0;
     if (!d_out_words || !d_workspace || (n_words && ((!d_in && !indexed) || !d_out))) {
         set_err("null pointer");
@@ -398,6 +399,12 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     a.n_segments = (uint32_t)l.n_segments;
     a.n_tiles = (uint32_t)l.n_tiles;
     a.wave_segs = l.wave_segs;
+    a.unseg_desc = nullptr;
+    if (unsegmented) { // fills cross the segment cut (compress_unseg_kernel): its own scan area, at most 4 segments per wave
+        a.unseg_desc = reinterpret_cast<uint32_t *>(ws + l.unseg_off);
+        if (a.wave_segs > (uint32_t)wah::kCompressUnsegMaxWaveSegs) a.wave_segs = wah::kCompressUnsegMaxWaveSegs;
+        a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
+    }
     if (indexed) { // groups come from two indexed streams (bitop_tile_kernel): its own tile shape
         a.wave_segs = wah::kIndexedSegsPerWave;
         a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * wah::kIndexedSegsPerWave);
@@ -412,7 +419,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     a.seg_offsets = d_segment_offsets;
     a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
     a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
-    a.scan_words = (l.total - l.desc_off) / sizeof(uint32_t);
+    a.scan_words = (l.total - l.desc_off) / sizeof(uint32_t); // both scan areas (the wrap-around clear covers them)
     a.keep_error = clear_first ? 1 : 0;
     a.host_result = host_result;
     {
@@ -458,6 +465,17 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
                                 size_t workspace_bytes, void *stream) {
     return compress_device_impl(d_in, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, d_segment_offsets,
                                 d_workspace, workspace_bytes, stream, false);
+}
+
+int wah_compress_device_ex(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
+                           uint64_t *d_out_words, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (flags & ~(unsigned)WAH_UNSEGMENTED) {
+        g_err[0] = 0;
+        set_err("unknown flag");
+        return WAH_ERR_ARG;
+    }
+    return compress_device_impl(d_in, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, nullptr, d_workspace,
+                                workspace_bytes, stream, false, nullptr, nullptr, (flags & WAH_UNSEGMENTED) != 0);
 }
 
 int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,

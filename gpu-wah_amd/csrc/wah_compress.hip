@@ -734,6 +734,372 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
     }
 }
 
+// ===========================================================================
+// Unsegmented ("classic") WAH straight out of the encoder (wah_compress_device_ex, WAH_UNSEGMENTED):
+// the stream that wah_merge_fills_device makes of compress()'s -- a fill may cross the 1024-group cut of
+// kernels.cu:68,188-229 (but not a multiple of 2^29 groups, so that every count fits 30 bits).
+//
+// Where the cut falls inside a run, segment s + 1 begins with the same fill group segment s ends with: a LOCAL property
+// of two groups.  The run's word is written by the segment in which the run ENDS; every earlier piece is dropped:
+//   drop_s   = the trailing fill of segment s continues into s + 1        -> segment s emits one word less (its last)
+//   merge_s  = the leading fill of segment s continues one from s - 1     -> its first word's count grows by carry_s
+// so the word counts stay ADDITIVE (count_s - drop_s) and the offsets come from the same row scan.  What crosses tiles
+// is the length of the run that is open at a tile's end -- and it only passes THROUGH tiles that are one single run
+// ("transparent", T): a tile publishes (T, L) beside its count, L = length of its trailing run (if T: its group count),
+//   carry_in(t) = L_j + sum of L over the transparent tiles between j and t,  j = nearest non-transparent tile before t
+// found in the same sweep (8-byte granules {epoch:16, count:16, T:1, L:17}; rows and superrows carry (T, L) in a second
+// slot array; the superrow prefix is an absolute length, which ends every walk).
+// ===========================================================================
+constexpr u32 kCutSegs = 1u << 19;                  // segments per block of 2^29 groups
+constexpr u64 kUnsegT = 1ull << 31;                 // granule: the tile is one single run that continues the one before it
+constexpr u64 kUnsegLMask = (1ull << 17) - 1ull;    // granule: length of the tile's trailing run
+constexpr u64 kSlotT = 1ull << 47;                  // slot B: the row is transparent
+constexpr u64 kSlotLMask = (1ull << 47) - 1ull;
+static_assert(kTileWaves * kCompressMaxWaveSegs * kSegGroups <= kUnsegLMask, "a tile's groups must fit the granule's L");
+static_assert(kUnsegBlockWords >= kUnsegSlotsBAt + 2 * kRowSlots && kUnsegSlotsAAt == 2 * kSuperRows * kRowTiles, "unsegmented scan block layout");
+
+__device__ __forceinline__ bool is_fill_group(u32 v) { return v == 0u || v == kOnes31; }
+
+struct UnsegSweep {
+    u32x4 a[2], b[2]; // granules of my row (entries below me) and of the previous row: four per lane
+    u64 ca, cb;       // slots A (words) and B (T, L) of my superrow: lane 0 = the prefix, lane 1 + k = row k
+};
+
+__device__ __forceinline__ void unseg_issue(u32 *block, u32 row_in_super, u32 idx, u32 n_slots, u32 lane, bool need_a, bool need_b,
+                                            bool need_c, UnsegSweep &p) {
+    if (need_a) {
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(block + (u64)row_in_super * kRowTiles * 2u, idx * 8u);
+        p.a[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 32u, 0, kAuxSc1);
+        p.a[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 32u + 16u, 0, kAuxSc1);
+    }
+    if (need_b) {
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(block + (u64)(row_in_super - 1u) * kRowTiles * 2u, kRowTiles * 8u);
+        p.b[0] = __builtin_amdgcn_raw_buffer_load_b128(rb, lane * 32u, 0, kAuxSc1);
+        p.b[1] = __builtin_amdgcn_raw_buffer_load_b128(rb, lane * 32u + 16u, 0, kAuxSc1);
+    }
+    if (need_c) {
+        const __amdgpu_buffer_rsrc_t rca = make_rsrc(block + kUnsegSlotsAAt, n_slots * 8u);
+        const __amdgpu_buffer_rsrc_t rcb = make_rsrc(block + kUnsegSlotsBAt, n_slots * 8u);
+        const u32x2 va = __builtin_amdgcn_raw_buffer_load_b64(rca, lane * 8u, 0, kAuxSc1);
+        const u32x2 vb = __builtin_amdgcn_raw_buffer_load_b64(rcb, lane * 8u, 0, kAuxSc1);
+        p.ca = ((u64)va.y << 32) | va.x;
+        p.cb = ((u64)vb.y << 32) | vb.x;
+    }
+}
+
+// Fold of up to four (T, L) entries per lane, entry k of lane l having sequence number 4 l + k, walked from the RIGHT:
+// returns whether all of them are transparent, and the sum of L from the nearest non-transparent entry (included) on.
+__device__ __forceinline__ bool fold_right(const bool (&valid)[4], const bool (&t)[4], const u64 (&len)[4], u32 lane, u64 &sum) {
+    u32 stop = 0; // 1 + index of my highest non-transparent entry
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (valid[k] && !t[k]) stop = (u32)k + 1u;
+    const u64 m = __ballot(stop != 0u);
+    u64 part = 0;
+    if (m == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) part += valid[k] ? len[k] : 0ull;
+        sum = uniform64(wave_sum(part));
+        return true;
+    }
+    const u32 hl = 63u - (u32)__builtin_clzll(m);
+    const u32 kk = (u32)__builtin_amdgcn_readlane((int)stop, (int)hl) - 1u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (valid[k] && (lane > hl || (lane == hl && (u32)k >= kk))) part += len[k];
+    sum = uniform64(wave_sum(part));
+    return false;
+}
+
+template <bool kAligned, u32 kWaveSegs>
+__device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
+    __shared__ __attribute__((aligned(16))) u32 s_out[kTileWaves][kOutWords];
+    __shared__ __attribute__((aligned(16))) unsigned short s_pos[kTileWaves][kPosEntries];
+    __shared__ u32 s_count[kTileWaves];
+    __shared__ u32 s_prefix[kTileWaves];
+    __shared__ u32 s_t[kTileWaves], s_l[kTileWaves]; // per wave: its segments are one continuing run / length of its trailing run
+    __shared__ u32 s_carry[kTileWaves];              // per wave: length of the run that is open where its first segment begins
+    __shared__ u64 s_base;
+    __shared__ u32 s_tile;
+
+    const u32 lane = lane_id();
+    const u32 wave = wave_id();
+    const u32 tile = draw_tile(a.ctrl, &s_tile);
+    const u32 seg0 = (tile * kTileWaves + wave) * kWaveSegs;
+    const LaunchEpoch le = launch_epoch_begin(a.ctrl, tile, a.gen_desc, a.scan_words, a.keep_error);
+    if (le.bad) {
+        if (tile == a.n_tiles - 1 && threadIdx.x == 0) *a.out_words = 0;
+        return;
+    }
+    const u32 epoch = le.epoch;
+
+    u32 *const stage = s_out[wave];
+    unsigned short *const pos = s_pos[wave];
+    u32 out[kWaveSegs][16];
+    u32 cnt[kWaveSegs], nval[kWaveSegs], first[kWaveSegs], last[kWaveSegs], tail[kWaveSegs];
+    bool single[kWaveSegs], merge[kWaveSegs], drop[kWaveSegs];
+    SegGroups grp[kWaveSegs];
+    SegEnds ends[kWaveSegs];
+    u32 never;
+    asm volatile("v_mov_b32 %0, -1" : "=v"(never));
+    BitmapSource<false, kAligned> src;
+    src.begin(a, seg0, kWaveSegs, lane);
+    // the group in front of the wave's first segment and the one behind its last: one word of the bitmap each
+    const u32 seg_next = seg0 + kWaveSegs;
+    u32 prev_last = 1u, next_first = 1u; // 1: not a fill group
+    if (seg0 > 0 && seg0 < a.n_segments) prev_last = a.in[(u64)seg0 * kSegWords - 1u] >> 1;
+    if (seg_next < a.n_segments) next_first = ((u64)seg_next * kSegWords < a.n_words ? a.in[(u64)seg_next * kSegWords] : 0u) & kOnes31;
+
+    // ---- pass 1 of all the wave's segments, and what each of them has at its two ends -----------------------------------
+#pragma unroll
+    for (u32 j = 0; j < kWaveSegs; ++j) {
+        const u32 seg = seg0 + j;
+        cnt[j] = 0;
+        nval[j] = kSegGroups;
+        first[j] = last[j] = 1u;
+        tail[j] = 0;
+        single[j] = false;
+        if (seg < a.n_segments) {
+            nval[j] = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
+            src.produce(a, seg, j + 1 < kWaveSegs, nval[j], stage, pos, lane, grp[j]);
+            const u32 raw = classify_pass1(grp[j], never, ends[j]);
+            cnt[j] = raw - (kSegGroups - nval[j]);
+            first[j] = uniform32(grp[j].x[0]);
+            if (nval[j] == kSegGroups) {
+                last[j] = (u32)__builtin_amdgcn_readlane((int)grp[j].x[kSteps - 1], 63);
+                single[j] = raw == 1u;
+                // length of the trailing run = distance from the last run end in front of group 1023 (flag word: bit 15 - s
+                // = group 64 s + lane ends a run; group 1023 always does)
+                const u32 fm = ends[j] & ~(lane == 63u ? 1u : 0u);
+                const u32 p1 = fm ? 64u * (15u - (u32)__builtin_ctz(fm)) + lane + 1u : 0u; // 1 + position of my last run end
+                const u32 mx = (u32)__builtin_amdgcn_readlane((int)wave_scan_max32(p1), 63);
+                tail[j] = is_fill_group(last[j]) ? kSegGroups - mx : 0u;
+            }
+        }
+    }
+    u32 count = 0, wave_t = 1u, wave_l = 0u;
+#pragma unroll
+    for (u32 j = 0; j < kWaveSegs; ++j) {
+        const u32 seg = seg0 + j;
+        merge[j] = drop[j] = false;
+        if (seg < a.n_segments) {
+            const u32 before = j ? last[j - 1] : prev_last;
+            merge[j] = seg > 0 && is_fill_group(before) && first[j] == before && (seg & (kCutSegs - 1u)) != 0u;
+            const u32 after = j + 1 < kWaveSegs ? first[j + 1] : next_first;
+            drop[j] = seg + 1 < a.n_segments && is_fill_group(last[j]) && after == last[j] && ((seg + 1u) & (kCutSegs - 1u)) != 0u;
+            count += cnt[j] - (drop[j] ? 1u : 0u);
+            if (single[j] && merge[j]) {
+                wave_l += kSegGroups;
+            } else {
+                wave_t = 0u;
+                wave_l = tail[j];
+            }
+        }
+    }
+    if (lane == 0) {
+        s_count[wave] = count;
+        s_t[wave] = wave_t;
+        s_l[wave] = wave_l;
+    }
+    __syncthreads();
+
+    // ---- wave 0: count and (T, L) of the tile go out in one granule, the sweep is issued ---------------------------------
+    const ScanGeom g = scan_geom(tile);
+    u32 *const block = a.unseg_desc + (u64)g.sup * kUnsegBlockWords;
+    u64 *const my_row = reinterpret_cast<u64 *>(block) + (u64)(g.row - g.row0) * kRowTiles;
+    UnsegSweep poll = {};
+    u32 total = 0, tile_t = 1u, tile_l = 0u;
+    if (wave == 0) {
+        const u32 mine = lane < kTileWaves ? s_count[lane] : 0u;
+        const u32 incl = wave_scan_incl32(mine);
+        if (lane < kTileWaves) s_prefix[lane] = incl - mine;
+        total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        for (u32 w = 0; w < kTileWaves; ++w) {
+            if (uniform32(s_t[w])) {
+                tile_l += uniform32(s_l[w]);
+            } else {
+                tile_t = 0u;
+                tile_l = uniform32(s_l[w]);
+            }
+        }
+        if (lane == 0)
+            __hip_atomic_store(my_row + g.idx, ((u64)epoch << 48) | ((u64)total << 32) | (tile_t ? kUnsegT : 0ull) | tile_l, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        unseg_issue(block, g.row - g.row0, g.idx, g.n_slots, lane, true, g.has_prev, true, poll);
+    }
+
+    // ---- pass 2 of all segments: compaction in LDS, final words into registers -----------------------------------------
+#pragma unroll
+    for (u32 j = 0; j < kWaveSegs; ++j) {
+        if (seg0 + j < a.n_segments) {
+            if (lane == 0) pos[0] = 0xFFFFu;
+            classify_pass2(grp[j], ends[j], stage, pos, lane, cnt[j] < kSparseBelow);
+            const bool any_fill = segment_has_fill(grp[j], cnt[j] + (kSegGroups - nval[j]), nval[j]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            final_words_to_regs(stage, pos, lane, cnt[j], any_fill, out[j]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+
+    if (wave == 0) {
+        // ---- the tile's offset and the run that is open where it begins ---------------------------------------------------
+        bool need_a = true, need_b = g.has_prev, need_c = true;
+        u64 words_a = 0, words_b = 0, words_c = 0, len_a = 0, len_b = 0, len_c = 0;
+        bool all_a = true, all_b = true;
+        u32 spins = 0;
+        auto granule = [](const u32x4 &q, int h) { return ((u64)(h ? q.w : q.y) << 32) | (h ? q.z : q.x); };
+        u64 *const slots_a = reinterpret_cast<u64 *>(block + kUnsegSlotsAAt);
+        u64 *const slots_b = reinterpret_cast<u64 *>(block + kUnsegSlotsBAt);
+        for (;;) {
+            u64 ba = 0, bb = 0, bc = 0;
+            u32 bad_a = 0, bad_b = 0;
+            bool bad_ca = false, bad_cb = false;
+            if (need_a) {
+                bool valid[4], t[4];
+                u64 len[4], sum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u64 gk = granule(poll.a[k >> 1], k & 1);
+                    valid[k] = 4u * lane + k < g.idx;
+                    if (valid[k] && (u32)(gk >> 48) != epoch) bad_a |= 1u << k;
+                    t[k] = (gk & kUnsegT) != 0;
+                    len[k] = gk & kUnsegLMask;
+                    sum += (gk >> 32) & 0xFFFFull; // entries at and above my index lie behind the descriptor and read as zero
+                }
+                ba = __ballot(bad_a != 0u);
+                if (ba == 0) {
+                    words_a = uniform64(wave_sum(sum));
+                    all_a = fold_right(valid, t, len, lane, len_a);
+                    need_a = false;
+                    if (g.idx == kRowTiles - 1u && lane == 0) { // my row is complete with me: its words and its (T, L)
+                        __hip_atomic_store(slots_a + 1u + (g.row - g.row0), ((u64)epoch << 48) | (words_a + total), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        const u64 row_tl = tile_t ? ((all_a ? kSlotT : 0ull) | (len_a + tile_l)) : (u64)tile_l;
+                        __hip_atomic_store(slots_b + 1u + (g.row - g.row0), ((u64)epoch << 48) | row_tl, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            if (need_b) {
+                bool valid[4], t[4];
+                u64 len[4], sum = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const u64 gk = granule(poll.b[k >> 1], k & 1);
+                    valid[k] = true;
+                    if ((u32)(gk >> 48) != epoch) bad_b |= 1u << k;
+                    t[k] = (gk & kUnsegT) != 0;
+                    len[k] = gk & kUnsegLMask;
+                    sum += (gk >> 32) & 0xFFFFull;
+                }
+                bb = __ballot(bad_b != 0u);
+                if (bb == 0) {
+                    words_b = uniform64(wave_sum(sum));
+                    all_b = fold_right(valid, t, len, lane, len_b);
+                    need_b = false;
+                }
+            }
+            if (need_c) {
+                // slots 0 of superrow 0 are never written: nothing lies in front of the first tile
+                const bool wanted = lane < g.n_slots && !(g.sup == 0u && lane == 0u);
+                bad_ca = wanted && (u32)(poll.ca >> 48) != epoch;
+                bad_cb = wanted && (u32)(poll.cb >> 48) != epoch;
+                bc = __ballot(bad_ca || bad_cb);
+                if (bc == 0) {
+                    words_c = uniform64(wave_sum(wanted ? poll.ca & ((1ull << 48) - 1ull) : 0ull));
+                    // walk from the right: lane 0 (the superrow prefix, an absolute length) ends it at the latest
+                    const bool stop = lane < g.n_slots && (lane == 0u || !(poll.cb & kSlotT));
+                    const u32 hl = 63u - (u32)__builtin_clzll(__ballot(stop));
+                    len_c = uniform64(wave_sum(wanted && lane >= hl ? poll.cb & kSlotLMask : 0ull));
+                    need_c = false;
+                }
+            }
+            if (!(need_a || need_b || need_c)) break;
+            if (++spins > kMaxSpins) {
+                if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
+                break;
+            }
+            // wait for the missing entry with the highest tile number, then read what is missing again
+            const u64 *target;
+            if (need_a) {
+                const u32 hl = 63u - (u32)__builtin_clzll(ba);
+                const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_a, (int)hl);
+                target = my_row + 4u * hl + (31u - (u32)__builtin_clz(km));
+            } else if (need_b) {
+                const u32 hl = 63u - (u32)__builtin_clzll(bb);
+                const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_b, (int)hl);
+                target = my_row - kRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
+            } else {
+                const u32 hl = 63u - (u32)__builtin_clzll(bc);
+                target = (uniform32(__shfl((u32)bad_ca, (int)hl)) ? slots_a : slots_b) + hl;
+            }
+            bool timed_out = false;
+            for (;;) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((u32)(__hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 48) == epoch) break;
+                if (++spins > kMaxSpins) {
+                    timed_out = true;
+                    break;
+                }
+            }
+            if (timed_out) {
+                if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
+                break;
+            }
+            unseg_issue(block, g.row - g.row0, g.idx, g.n_slots, lane, need_a, need_b, need_c, poll);
+        }
+        const u64 base = words_c + words_b + words_a;
+        const u64 end = base + total;
+        // the run that is open in front of this tile: through my row, the previous one, the older rows, the prefix
+        u64 carry = len_a;
+        if (all_a) carry += g.has_prev ? (all_b ? len_b + len_c : len_b) : len_c;
+        u64 c = carry;
+        for (u32 w = 0; w < kTileWaves; ++w) {
+            if (lane == 0) s_carry[w] = (u32)c;
+            c = uniform32(s_t[w]) ? c + uniform32(s_l[w]) : (u64)uniform32(s_l[w]);
+        }
+        if (lane == 0) {
+            s_base = base;
+            if (g.idx == kRowTiles - 1u && g.row - g.row0 == kSuperRows - 1u) { // last tile of a superrow: the next one's prefix
+                u32 *const nb = a.unseg_desc + (u64)(g.sup + 1u) * kUnsegBlockWords;
+                __hip_atomic_store(reinterpret_cast<u64 *>(nb + kUnsegSlotsAAt), ((u64)epoch << 48) | end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<u64 *>(nb + kUnsegSlotsBAt), ((u64)epoch << 48) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tile == a.n_tiles - 1) {
+                *a.out_words = end;
+                if (end > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+                if (a.host_result) {
+                    a.host_result[1] = end;
+                    a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
+                }
+                launch_epoch_end(a.ctrl, le);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- the parked words to their place: a continuing leading fill gets the open run's length, a continuing trailing
+    //      fill is left to the segment in which the run ends ------------------------------------------------------------------
+    u64 base = uniform64(s_base) + uniform32(s_prefix[wave]);
+    u32 c = uniform32(s_carry[wave]);
+#pragma unroll
+    for (u32 j = 0; j < kWaveSegs; ++j) {
+        if (seg0 + j < a.n_segments) {
+            const u32 ci = merge[j] ? c : 0u;
+            if (lane == 0) out[j][0] += ci; // (count of the leading fill; ci = 0 otherwise)
+            const u32 n_out = cnt[j] - (drop[j] ? 1u : 0u);
+            emit_regs(a, base, n_out, lane, out[j]);
+            base += n_out;
+            c = single[j] && merge[j] ? ci + kSegGroups : tail[j];
+        }
+    }
+}
+
+template <bool kAligned, u32 kWaveSegs>
+__global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compress_unseg_kernel(const CompressArgs a) {
+    compress_unseg_body<kAligned, kWaveSegs>(a);
+}
+
 template <bool kPair, bool kAligned, u32 kWaveSegs>
 __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compress_tile_kernel(const CompressArgs a) {
     BitmapSource<kPair, kAligned> src;
@@ -772,7 +1138,24 @@ static void launch_tiles(const CompressArgs &a, hipStream_t s) {
     }
 }
 
+template <bool kAligned>
+static void launch_unseg(const CompressArgs &a, hipStream_t s) {
+    const dim3 grid(a.n_tiles), block(kTileWaves * 64);
+    switch (a.wave_segs) {
+    case 1: hipLaunchKernelGGL((compress_unseg_kernel<kAligned, 1>), grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((compress_unseg_kernel<kAligned, 2>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((compress_unseg_kernel<kAligned, 4>), grid, block, 0, s, a); break;
+    }
+}
+
 hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {
+    if (a.unseg_desc) {
+        if (a.fast_segments)
+            launch_unseg<true>(a, s);
+        else
+            launch_unseg<false>(a, s);
+        return hipGetLastError();
+    }
     if (a.in2)
         launch_tiles<true, true>(a, s);
     else if (a.fast_segments)

@@ -111,6 +111,15 @@ int wah_workspace_init_device(void *d_workspace, size_t workspace_bytes, void *s
 int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
                         uint64_t *d_out_words, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* The same with flags.  WAH_UNSEGMENTED: classic WAH straight out of the encoder -- a fill may cross the 1024-group
+ * segment cut of the reference (kernels.cu:68,188-229; never a multiple of 2^29 groups, so that every count fits 30
+ * bits): exactly the stream wah_merge_fills_device makes of wah_compress_device's, in the one pass.  It
+ * decodes to the same bitmap with wah_decompress*; it is not what the reference's encoder emits and has no segment
+ * index. */
+#define WAH_UNSEGMENTED 1u
+int wah_compress_device_ex(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
+                           uint64_t *d_out_words, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* Optional side output: when d_segment_offsets != NULL it receives, for every
  * 992-word segment s, the index of its first compressed word
  * (n_segments + 1 entries, the last one = C).  This is the reference's scanned

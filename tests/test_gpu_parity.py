@@ -356,6 +356,53 @@ def test_merge_fills_unsegmented_form(wah, oracle):
     assert not wah.validate_device(wah.merge_fills_device(_dev(z))).segment_canonical
 
 
+def test_unsegmented_encoder_mode(wah, oracle):
+    """wah_compress_device_ex(..., WAH_UNSEGMENTED) == merge_fills(compress(x)), bit for bit, in the one pass: runs that
+    cross segments, waves, tiles, rows of tiles, and (last case) a superrow of tiles and the 2^29-group cut."""
+    import torch
+
+    rng = np.random.default_rng(11)
+
+    def islands(n, k, seed):  # zeros (or ones) with k short random islands: long runs through many transparent tiles
+        x = np.zeros(n, np.uint32) if seed % 2 else np.full(n, 0xFFFFFFFF, np.uint32)
+        for p in np.random.default_rng(seed).integers(0, n - 40, k):
+            x[p: p + 37] = np.random.default_rng(seed + int(p)).integers(0, 2**32, 37, dtype=np.uint64).astype(np.uint32)
+        return x
+
+    alternating = np.zeros(992 * 64, np.uint32)
+    alternating.reshape(64, 992)[1::2] = 0xFFFFFFFF
+    cases = [np.zeros(992 * 700 + 3, np.uint32), np.full(992 * 333, 0xFFFFFFFF, np.uint32), oracle.gen_uniform(992 * 900, 2, 2.0**-14),
+             oracle.gen_clustered(992 * 600 + 11, 3, 50000), oracle.gen_uniform(992 * 40, 4, 0.3), alternating,
+             islands(992 * 30000, 9, 1), islands(992 * 30000 + 77, 40, 2), islands(992 * 9000, 3, 3), np.zeros(31, np.uint32),
+             oracle.gen_clustered(992 * 30000, 5, 2_000_000)]
+    for x in cases:
+        comp = wah.DeviceCompressor(len(x), unsegmented=True)
+        comp.run(_dev(x))
+        got = _host(comp.result())
+        want = _py_merge_fills(oracle.compress(x))
+        assert np.array_equal(got, want), (len(x), len(got), len(want))
+        back = _host(wah.decompress_device(comp.result().clone(), len(x) + 1))
+        assert np.array_equal(back[: len(x)], x)
+        del comp
+    # 600 000 all-zero segments: the run crosses rows and a superrow of tiles and is cut at 2^29 groups (segment 524 288)
+    n = 992 * 600000
+    z = torch.zeros(n, dtype=torch.int32, device="cuda")
+    comp = wah.DeviceCompressor(n, unsegmented=True)
+    comp.run(z)
+    assert _host(comp.result()).tolist() == [0x80000000 | (1 << 29), 0x80000000 | ((600000 - 524288) * 1024)]
+    z[992 * 524288 - 5] = 7  # a literal just in front of the cut, ones behind it
+    z[992 * 524288:] = -1
+    comp.run(z)
+    got = _host(comp.result())
+    want = _py_merge_fills(oracle.compress(z.cpu().numpy().view(np.uint32)))
+    assert np.array_equal(got, want)
+    # an unsegmented stream has no segment index, and unknown flags are refused
+    with pytest.raises(wah.WahError):
+        wah.DeviceCompressor(992, indexed=True, unsegmented=True)
+    assert wah.lib().wah_compress_device_ex(z.data_ptr(), 992, comp.out.data_ptr(), comp.capacity, comp.count.data_ptr(), 6,
+                                            comp.workspace.data_ptr(), comp.ws_bytes, None) == -1
+
+
 # ---------------------------------------------------------------- bitwise operations on compressed bitmaps
 def test_bitops_on_compressed_bitmaps(wah, oracle):
     """wah_bitop_device(op, A, B) == compress(decompress(A) op decompress(B)), for whole-segment and ragged lengths."""
