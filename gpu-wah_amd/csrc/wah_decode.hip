@@ -108,8 +108,14 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
         for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + 1024u * k, 0, 0);
     };
     constexpr u32 kRounds = 4u * kWaveTiles;
-    u32x4 cur[4], nxt[4];
-    if (round_whole(0)) issue_round(0, cur);
+#ifndef WAH_SUM_AHEAD
+#define WAH_SUM_AHEAD 1
+#endif
+    constexpr u32 kAhead = WAH_SUM_AHEAD; // rounds in flight behind the one being summed
+    u32x4 buf[kAhead + 1][4];
+#pragma unroll
+    for (u32 rd = 0; rd < kAhead && rd < kRounds; ++rd)
+        if (round_whole(rd)) issue_round(rd, buf[rd % (kAhead + 1)]);
     u64 mine = 0;
     bool has_empty = false;
 #pragma unroll
@@ -117,7 +123,8 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
         const u32 et = et0 + rd / 4u;
         if (et < n_tiles) {
             if (round_whole(rd)) {
-                if (rd + 1u < kRounds && round_whole(rd + 1u)) issue_round(rd + 1u, nxt);
+                if (rd + kAhead < kRounds && round_whole(rd + kAhead)) issue_round(rd + kAhead, buf[(rd + kAhead) % (kAhead + 1)]);
+                const u32x4(&cur)[4] = buf[rd % (kAhead + 1)];
                 u32 lo = 1;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { // four counts of < 2^30 each fit 32 bits
@@ -126,8 +133,6 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
                     lo = min(min(lo, min(nx, ny)), min(nz, nw));
                 }
                 has_empty |= lo == 0u;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
             } else { // the stream's last rounds, or a stream that is only 4-byte aligned: word by word, bounds checked
                 const u64 w0 = (u64)et0 * kScanTileWords + (u64)rd * 1024u;
                 for (u32 i = lane; i < 1024u; i += 64u) {
@@ -765,9 +770,12 @@ __global__ __launch_bounds__(kSegDecodeWaves * 64, 6) void bitop_many_segments_k
 
 hipError_t launch_decode_sums(const ScanArgs &a, hipStream_t s) {
     // long streams: four expand tiles per wave (ticket, barrier and scan once per 512 KiB); short ones: more workgroups
+#ifndef WAH_SUM_TILES
+#define WAH_SUM_TILES 4
+#endif
     if (a.n_tiles >= 16384) {
-        const u64 wg_tiles = (a.n_tiles + kSumWaves * 4 - 1) / (kSumWaves * 4);
-        hipLaunchKernelGGL(decode_sums_kernel<4>, dim3((unsigned)wg_tiles), dim3(kSumWaves * 64), 0, s, a);
+        const u64 wg_tiles = (a.n_tiles + kSumWaves * WAH_SUM_TILES - 1) / (kSumWaves * WAH_SUM_TILES);
+        hipLaunchKernelGGL(decode_sums_kernel<WAH_SUM_TILES>, dim3((unsigned)wg_tiles), dim3(kSumWaves * 64), 0, s, a);
     } else {
         const u64 wg_tiles = (a.n_tiles + kSumWaves - 1) / kSumWaves;
         hipLaunchKernelGGL(decode_sums_kernel<1>, dim3((unsigned)wg_tiles), dim3(kSumWaves * 64), 0, s, a);
