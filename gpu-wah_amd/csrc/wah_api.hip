@@ -232,6 +232,15 @@ struct HostCall {
         return hipEventCreate(&ev[0]) == hipSuccess && hipEventCreate(&ev[1]) == hipSuccess;
     }
     void start() { (void)hipEventRecord(ev[0], nullptr); }
+    // end of a phase that ends with device work: the event goes into the stream right behind the launch, so that it
+    // carries the time at which the device finished, not the time at which the host noticed
+    void mark() { (void)hipEventRecord(ev[1], nullptr); }
+    float since_mark() {
+        float ms = 0.f;
+        (void)hipEventSynchronize(ev[1]);
+        (void)hipEventElapsedTime(&ms, ev[0], ev[1]);
+        return ms;
+    }
     float stop() {
         float ms = 0.f;
         (void)hipEventRecord(ev[1], nullptr);
@@ -1006,13 +1015,14 @@ uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *ou
     host_result[0] = 0;
     int rc = compress_device_impl(static_cast<uint32_t *>(d_in), nullptr, 0, nullptr, n_words, static_cast<uint32_t *>(d_out), cap, d_cnt,
                                   nullptr, d_ws, ws_bytes, nullptr, false, n_words ? host_result : nullptr);
+    hc.mark();
     uint64_t c = 0;
     if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws, hc.cache.pinned, &c, 1); // status + size: one wait, no copy
     if (rc != WAH_OK) {
         std::fprintf(stderr, "wah: compress failed: %s\n", g_err);
         return nullptr;
     }
-    t_dev = hc.stop();
+    t_dev = hc.since_mark();
 
     // phase 3: D2H + free (compress.cu:177-202)
     hc.start();
@@ -1084,12 +1094,13 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     // the tile bases of the scan are still in the workspace: expand only
     rc = wah_decompress_expand_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(d_out), n_out, d_info,
                                       d_ws0, ws0, nullptr);
+    hc.mark();
     if (rc == WAH_OK) rc = read_status_packed(d_ws0, hc.cache.pinned, nullptr, 0);
     if (rc != WAH_OK) {
         std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
         return nullptr;
     }
-    t_dev = hc.stop();
+    t_dev = hc.since_mark();
 
     // phase 3: D2H + free (decompress.cu:124-131).  The reference hands back a buffer of G words
     // (one per group) of which ceil(31 G / 32) are meaningful; we keep the size and zero the rest.
