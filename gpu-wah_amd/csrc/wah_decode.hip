@@ -105,7 +105,8 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
     auto issue_round = [&](u32 rd, u32x4 (&v)[4]) {
         const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.comp + (u64)et0 * kScanTileWords + (u64)rd * 1024u, 4096u);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + 1024u * k, 0, 0);
+        // nontemporal (aux = 2), as the compress kernel's loads of the bitmap (wah_compress.hip: load16)
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16u + 1024u * k, 0, 2);
     };
     constexpr u32 kRounds = 4u * kWaveTiles;
 #ifndef WAH_SUM_AHEAD
@@ -567,6 +568,7 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
         uint4 *dst = reinterpret_cast<uint4 *>(s_words);
         uint4 v[kVec];
 #pragma unroll
+        // (default cache policy: nontemporal loads here made the round trip slower, 1469 -> 1423 GB/s on the sparse GiB)
         for (int k = 0; k < kVec; ++k) v[k] = src[k * kExpandThreads + (int)threadIdx.x]; // coalesced 16-byte loads
 #pragma unroll
         for (int k = 0; k < kVec; ++k) dst[k * kExpandThreads + (int)threadIdx.x] = v[k];
