@@ -363,6 +363,7 @@ __device__ __forceinline__ void emit_regs(const CompressArgs &a, u64 base, u32 c
     for (int t = 0; t < 4; ++t) {
         if (256u * t < count) {
 #pragma unroll
+            // (default cache policy: nontemporal stores gave +2 % on the sparse round trip, -3 % on the clustered one)
             for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(out[4 * t + k], rsrc, off + 256u * (4 * t + k), 0, 0);
         }
     }
