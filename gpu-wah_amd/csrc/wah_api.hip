@@ -402,7 +402,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
         }
         return WAH_OK;
     }
-    wah::CompressArgs a;
+    wah::CompressArgs a{};
     a.in = d_in;
     a.n_words = n_words;
     a.n_segments = (uint32_t)l.n_segments;
@@ -431,13 +431,15 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     a.scan_words = (l.total - l.desc_off) / sizeof(uint32_t); // both scan areas (the wrap-around clear covers them)
     a.keep_error = clear_first ? 1 : 0;
     a.host_result = host_result;
+#ifdef WAH_DIAG
     {
-        static const uint32_t tune = [] {
+        static const uint32_t tune = [] { // diagnostic build only: 77 / 78 = per-tile time line (tools/tile_timeline.py)
             const char *e = std::getenv("WAH_TUNE");
             return e ? (uint32_t)std::strtoul(e, nullptr, 0) : 0u;
         }();
         a.tune = tune;
     }
+#endif
     a.in2 = d_in2;
     a.op = (uint32_t)op;
     if (d_in2) {

@@ -26,21 +26,10 @@ namespace wah {
 namespace {
 
 // ===========================================================================
-// compress
-//
-// Workgroup = W worker wavefronts + 1 scan wavefront, persistent, no barrier after start-up.
-//   worker w : owns segment tile*W + w.  Per iteration g: the 4 x 16-byte loads of its segment were issued an
-//              iteration earlier (software prefetch); it stages them in its private 4 KiB STAGE buffer, issues the
-//              next tile's loads, classifies, compacts the run-end words in place, delivers their count, and turns
-//              them into final WAH words (fill length = distance between consecutive run ends) written to its
-//              private 4 KiB RING behind the words of earlier tiles that still wait for their output offset.
-//              Whenever the offset of the oldest tile in the ring is known it is streamed out with dense 256-byte
-//              stores (kernels.cu:256 + moveData).
-//   scan wave: never touches bitmap data, so its memory queue only holds granule traffic.  Takes the tile's word
-//              count from the last worker to deliver, resolves the tile's offset with the one-hop generation scan
-//              above and hands it to the workers through LDS.
-// Offsets are therefore needed two to four iterations after the counts were published (one for incompressible
-// data, where a tile fills the ring), which absorbs the resolve latency and the jitter between 256 workgroups.
+// compress: per-segment building blocks (loads, regrouping, the two classify passes, final words); the tile kernel
+// that strings them together and its offset scan are described further down, at compress_tile_kernel.
+// Per wave and segment in LDS: a 4 KiB STAGE buffer (the 992 input words, later the compacted run-end words in place)
+// and a 2 KiB position array (kernels.cu:126-141 run ends, :188-229 merge, :244-259 final words).
 // ===========================================================================
 constexpr u32 kStageWords = 1024; // staged segment (992 words + look-ahead) / compacted output words (<= 1024), aliased
 constexpr u32 kOutWords = kStageWords + 4; // + one dump dword (non-end lanes), kept 16-byte aligned
@@ -232,14 +221,16 @@ __device__ __forceinline__ void classify_pass2(const SegGroups &g, SegEnds e, u3
 // compress_tile_kernel
 //
 // Workgroup = one TILE of kTileWaves x kWaveSegs consecutive segments, short-lived; tile = arrival order (draw_tile).
-//   every wave : 4 x 16-byte loads of its segment -> private 4 KiB LDS stage -> classify + compact in place
-//                (classify_compact) -> count to LDS -> barrier -> [wave 0: row scan] -> barrier -> final words
-//                (fill length = distance between consecutive run ends) straight from LDS to their place in the
-//                output with dense 256-byte stores (kernels.cu:244-259 + moveData, kernels.cu:273-280).
-//   wave 0     : additionally resolves the tile's output offset with the ROW SCAN below.  Its granule loads are
-//                issued BEFORE it classifies its own segment, so they come back about when the count is known.
-// Nothing is persistent: no residency census, no arrival tickets, nothing to clear between launches, and a wave
-// that waits at the barrier issues no instructions (the SIMDs of this kernel are bound by instruction issue).
+//   every wave : for each of its kWaveSegs segments: 4 x 16-byte loads -> LDS stage -> 16 groups per lane in registers
+//                -> PASS 1 (run ends counted, one flag word per lane kept) ; counts to LDS -> barrier ->
+//                PASS 2 for every segment (rank + compact the run-end words in LDS) and the final words (fill length
+//                = distance between consecutive run ends) parked in registers -> barrier -> dense 256-byte stores to
+//                their place in the output (kernels.cu:244-259 + moveData, kernels.cu:273-280).
+//   wave 0     : additionally publishes the tile's count right after the first barrier and resolves the tile's
+//                output offset with the ROW SCAN below; the sweep is in flight while all waves run pass 2.
+// Nothing is persistent: no residency census, nothing to clear between launches (launch epochs, below); the only
+// shared counter is the arrival ticket a workgroup draws its tile number from.  A wave that waits at the barrier
+// issues no instructions; the kernel is bound by the latency of the offset hop, not by instruction issue.
 //
 // Row scan (replaces thrust::exclusive_scan + the two blocking 8-byte reads of compress.cu:133-157).
 //   granule[t]           u32 {epoch:16, words:16} of tile t, published as soon as the tile's words are counted
@@ -560,7 +551,7 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
 #endif
     }
 
-    // ---- pass 2 of both segments: compaction in LDS, final words into registers -------------------------------------
+    // ---- pass 2 of all the wave's segments: compaction in LDS, final words into registers -------------------------------------
 #pragma unroll
     for (u32 j = 0; j < kWaveSegs; ++j) {
         if (seg0 + j < a.n_segments) {

@@ -31,7 +31,8 @@ namespace {
 //   granule[r][0 .. i)  +  granule[r-1][0 .. 256)  +  slot[s][1 ..] of rows s0 .. r-2  +  slot[s][0]
 // (rows of 256 workgroup tiles, superrows of 64 rows; a row's last tile publishes the row's slot, a superrow's last tile
 // the next superrow's slot[0]) and writes the exclusive bases of its eight expand tiles.  Nothing is persistent: no
-// residency census, no arrival tickets; launch epochs (wah_device.hpp) instead of clearing; every wait is bounded.
+// residency census; the arrival ticket is the only shared counter; launch epochs (wah_device.hpp) instead of clearing;
+// every wait is bounded.
 // Totals saturate at 2^47 groups (a stream that claims more -- 500 TB of bitmap -- is reported as WAH_ERR_STREAM).
 constexpr u32 kSumWaves = (u32)kSumTilesPerGroup;
 constexpr u32 kSumRowTiles = 256;

@@ -89,7 +89,7 @@ struct CompressArgs {
     int keep_error;        // 1: the control block was cleared by the caller and may already hold an upstream error
     uint64_t *host_result; // optional, page-locked HOST memory: [0] = 1 | error bits << 32, [1] = C, written by the last tile
                            // (the host-pointer entry points read them after one event wait, without a copy)
-    uint32_t tune;         // experiments only (WAH_TUNE)
+    uint32_t tune;         // WAH_DIAG builds only (WAH_TUNE): time line modes of tools/tile_timeline.py; 0 otherwise
 };
 
 struct ScanArgs {
