@@ -285,6 +285,14 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
     }
 }
 
+// The LDS image of a tile is followed by room for the words BEHIND the tile that its last segment needs (a segment
+// starts inside the tile and takes at most 1024 words from there; marking reads whole batches of 128): the mark
+// phase parks them there as it reads them, so that the expansion gathers every word from LDS.  Gathering them from
+// global memory -- one dependent load per step, and on this hardware a load also waits for every older STORE of the
+// wavefront (one counter for both) -- made the tile's last segment its slowest by far: 0.426 -> 0.395 ms on the sparse GiB.
+constexpr u32 kTileBehind = kSegGroups + 128u;
+constexpr u32 kTileLdsWords = (u32)kScanTileWords + kTileBehind;
+
 // word `idx` (tile-local index) of the stream: LDS inside the tile, global memory past its end
 __device__ __forceinline__ u32 tile_word(const u32 *s_words, const ExpandArgs &a, u64 tile_w0, u32 idx) {
     if (idx < (u32)kScanTileWords) return s_words[idx];
@@ -310,28 +318,42 @@ __device__ __forceinline__ void expand_steps(const ExpandArgs &a, const u32 *s_w
     // lanes 31 and 63 only lend their group.
     const u32 o = lane & 31u;
     const u32 up = 31u - ((lane - 1u) & 31u);             // what my group is shifted up by in my LEFT neighbour's word
-    const u32 soff = o != 31u ? (lane - (lane >> 5)) * 4u : 0xFFFFF000u; // lanes 31, 63: out of range, dropped
+    u32 soff = o != 31u ? (lane - (lane >> 5)) * 4u : 0xFFFFF000u; // lanes 31, 63: out of range, dropped
+    // (opaque: otherwise the sixteen store offsets soff + 248 s are computed once per kernel and sit in sixteen registers
+    //  for its whole life instead of being the instructions' immediate offsets)
+    asm volatile("" : "+v"(soff));
     const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
     const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
     u32 before4 = (first_word - 1u) * 4u;                 // byte offset of (first_word + flags in earlier steps - 1)
+    // four steps at a time: their ranks first, then the four gathers together, then decode and store
 #pragma unroll
-    for (int s = 0; s < (int)kSteps; ++s) {
-        const u32 fb = (f[s >> 2] >> (8 * (s & 3))) & 0xFFu;  // 1: a word starts at my group
-        const u64 m = __ballot(fb != 0u);
-        // inclusive rank among this step's flags (the count is seeded with my own flag), plus all earlier ones
-        const u32 r4 = (__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, fb)) << 2) + before4;
-        before4 = (u32)__builtin_amdgcn_readlane((int)r4, 63); // the last lane's rank counts every flag so far
-        const u32 src_word = kLocal ? *reinterpret_cast<const u32 *>(reinterpret_cast<const unsigned char *>(s_words) + r4)
-                                    : tile_word(s_words, a, tile_w0, r4 >> 2);
-        // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354)
-        const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
-        u32 grp = (int)src_word < 0 ? fill_val : src_word;
-        if (!kWhole && (u32)(64 * s) + lane >= nvalid) grp = 0u;
-        const u32 hi_part = (u32)__builtin_amdgcn_mov_dpp((int)(grp << up), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-        const u32 word = (grp >> o) | hi_part;
-        // (default cache policy: nontemporal stores here cost the clustered round trip 22 % -- the memory-side cache combines
-        //  this kernel's 248-byte stores)
-        __builtin_amdgcn_raw_buffer_store_b32(word, rsrc, soff + 248u * s, 0, 0);
+    for (int g = 0; g < (int)kSteps / 4; ++g) {
+        u32 r4[4], src_word[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32 fb = (f[g] >> (8 * q)) & 0xFFu;     // 1: a word starts at my group
+            const u64 m = __ballot(fb != 0u);
+            // inclusive rank among this step's flags (the count is seeded with my own flag), plus all earlier ones
+            r4[q] = (__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, fb)) << 2) + before4;
+            before4 = (u32)__builtin_amdgcn_readlane((int)r4[q], 63); // the last lane's rank counts every flag so far
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            src_word[q] = kLocal ? *reinterpret_cast<const u32 *>(reinterpret_cast<const unsigned char *>(s_words) + r4[q])
+                                 : tile_word(s_words, a, tile_w0, r4[q] >> 2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int s = 4 * g + q;
+            // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354)
+            const u32 fill_val = (u32)((int)(src_word[q] << 1) >> 31) & kOnes31;
+            u32 grp = (int)src_word[q] < 0 ? fill_val : src_word[q];
+            if (!kWhole && (u32)(64 * s) + lane >= nvalid) grp = 0u;
+            const u32 hi_part = (u32)__builtin_amdgcn_mov_dpp((int)(grp << up), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+            const u32 word = (grp >> o) | hi_part;
+            // (default cache policy: nontemporal stores here cost the clustered round trip 22 % -- the memory-side cache
+            //  combines this kernel's 248-byte stores)
+            __builtin_amdgcn_raw_buffer_store_b32(word, rsrc, soff + 248u * s, 0, 0);
+        }
     }
 }
 
@@ -348,7 +370,10 @@ __device__ __forceinline__ void expand_emit(const ExpandArgs &a, const u32 *s_wo
         else
             expand_steps<true, false>(a, s_words, flag, tile_w0, rsrc, first_word, nvalid, lane);
     } else {
-        expand_steps<false, false>(a, s_words, flag, tile_w0, rsrc, first_word, nvalid, lane);
+        if (local)
+            expand_steps<false, true>(a, s_words, flag, tile_w0, rsrc, first_word, nvalid, lane);
+        else
+            expand_steps<false, false>(a, s_words, flag, tile_w0, rsrc, first_word, nvalid, lane);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
@@ -473,7 +498,7 @@ __device__ __forceinline__ void expand_segment_with_empties(const ExpandArgs &a,
 // segment start (<= 0 at first).  Flags the group at which every contributing word starts (clipped at the segment
 // start).  kFirst: returns the tile-local index of the first contributing word.
 template <bool kLocal, bool kFirst>
-__device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, const u32 *s_words, unsigned char *flag, u64 tile_w0,
+__device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, u32 *s_words, unsigned char *flag, u64 tile_w0,
                                           u32 left_in_stream, u32 nvalid, u32 lane, int &rel, u32 &wi) {
     const u32 i0 = wi + 2u * lane;
     u32 w0, w1;
@@ -484,6 +509,8 @@ __device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, const u32 *s_word
     } else { // past the tile: global memory; past the stream: empty fills
         w0 = i0 < left_in_stream ? a.comp[tile_w0 + i0] : 0x80000000u;
         w1 = i0 + 1u < left_in_stream ? a.comp[tile_w0 + i0 + 1u] : 0x80000000u;
+        // parked behind the tile for the expansion (words of the tile itself are written again with the same values)
+        if (i0 + 1u < kTileLdsWords) *reinterpret_cast<uint2 *>(s_words + i0) = make_uint2(w0, w1);
     }
     const u32 n0 = word_groups(w0), n1 = word_groups(w1);
     // all literals (dense data): consecutive positions, no scan; otherwise one DPP scan over the pair sums
@@ -511,7 +538,7 @@ __device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, const u32 *s_word
     return first;
 }
 
-__device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, const u32 *s_words, const u32 *s_coarse32,
+__device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, u32 *s_words, const u32 *s_coarse32,
                                                     unsigned char *flag, u64 tile_w0, u32 target, u32 nvalid,
                                                     u64 out_words, u64 seg, u32 lane) {
     // 64-ary search over the coarse prefix: last 64-word bucket that starts at or before the target
@@ -538,11 +565,11 @@ __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, const u
         return;
     }
     // group g belongs to the r-th contributing word, r = (flags at positions <= g) - 1
-    expand_emit(a, s_words, flag, tile_w0, first_word, nvalid, out_words, seg, wi <= (u32)kScanTileWords, lane);
+    expand_emit(a, s_words, flag, tile_w0, first_word, nvalid, out_words, seg, wi <= kTileLdsWords, lane);
 }
 
 __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const ExpandArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 s_words[kScanTileWords];
+    __shared__ __attribute__((aligned(16))) u32 s_words[kTileLdsWords];
     __shared__ u64 s_coarse[kCoarse + 1]; // groups in front of word 64 c, relative to the tile start
     __shared__ u32 s_coarse32[kCoarse + 1]; // the same in 32 bits (valid when the tile total is below 2^31)
     __shared__ u64 s_wave_sum[kExpandWaves];
@@ -551,6 +578,9 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
     const u32 lane = lane_id();
     const u32 wave = wave_id();
     // a stream of few tiles (highly compressed data) expands to many segments per tile: `parts` workgroups share a tile
+#ifdef WAH_DIAG
+    const u64 dg_start = __builtin_amdgcn_s_memrealtime();
+#endif
     const u32 tile = blockIdx.x / a.parts;
     const u32 part = blockIdx.x % a.parts;
     const u64 tile_w0 = (u64)tile * kScanTileWords;
@@ -606,6 +636,9 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
     }
     __syncthreads();
 
+#ifdef WAH_DIAG
+    const u64 dg_ready = __builtin_amdgcn_s_memrealtime();
+#endif
     // ---- segments owned by this tile: those whose first group lies in [base, base + total) ----------------------
     const u64 base = a.tile_base[tile];
     const u64 total = uniform64(s_coarse[kCoarse]);
@@ -635,6 +668,16 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
             expand_segment_general(a, s_words, s_coarse, flag, tile_w0, base, groups, out_words, seg, lane);
         }
     }
+#ifdef WAH_DIAG
+    __syncthreads();
+    if (wave == 0 && lane == 0 && tile % 67u == 0u) { // a sample (tools/decode_phases.py): 100 MHz stamps
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(a.ctrl + 192);
+        const u64 now = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(d + 0, (unsigned long long)(dg_ready - dg_start)); // tile staged, coarse prefix built
+        atomicAdd(d + 1, (unsigned long long)(now - dg_ready));      // the tile's segments expanded
+        atomicAdd(d + 2, 1ull);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
