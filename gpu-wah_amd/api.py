@@ -206,11 +206,15 @@ class DeviceCompressor:
     allocated inside run(), so it can be timed (and graph-captured) as pure device work.
     """
 
-    def __init__(self, n_words, device="cuda:0", indexed=False, unsegmented=False):
+    def __init__(self, n_words, device="cuda:0", indexed=False, unsegmented=False, no_wait=False):
+        """no_wait: the three-launch route in which no workgroup waits for another (include/wah.h: WAH_NO_WAIT)."""
         torch = _torch()
         if indexed and unsegmented:
             raise WahError("an unsegmented stream has no segment index")
+        if no_wait and (indexed or unsegmented):
+            raise WahError("WAH_NO_WAIT applies to the plain compress only")
         self.unsegmented = bool(unsegmented)
+        self.no_wait = bool(no_wait)
         self.n_words = int(n_words)
         self.capacity = max_compressed_words(self.n_words)
         self.ws_bytes = int(lib().wah_compress_workspace_bytes(self.n_words))
@@ -229,9 +233,9 @@ class DeviceCompressor:
         if n > self.n_words or n > d_in.numel():
             raise WahError("input larger than this compressor was sized for")
         sp = _stream_ptr(torch, stream)
-        if self.unsegmented:
-            rc = lib().wah_compress_device_ex(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, self.count.data_ptr(), 1,
-                                              self.workspace.data_ptr(), self.ws_bytes, sp)
+        if self.unsegmented or self.no_wait:
+            rc = lib().wah_compress_device_ex(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, self.count.data_ptr(),
+                                              1 if self.unsegmented else 2, self.workspace.data_ptr(), self.ws_bytes, sp)
         elif self.seg_offsets is None:
             rc = lib().wah_compress_device(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, self.count.data_ptr(),
                                            self.workspace.data_ptr(), self.ws_bytes, sp)

@@ -367,8 +367,19 @@ size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_wo
 static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int op, const wah::PairCheck *check, uint64_t n_words,
                                 uint32_t *d_out, uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_segment_offsets,
                                 void *d_workspace, size_t workspace_bytes, void *stream, bool clear_first,
-                                uint64_t *host_result = nullptr, const wah::BitopOperands *indexed = nullptr, bool unsegmented = false) {
+                                uint64_t *host_result = nullptr, const wah::BitopOperands *indexed = nullptr, bool unsegmented = false,
+                                bool no_wait = false) {
     g_err[0] = 0;
+    // WAH_FORCE_FALLBACK=1: every plain compress launch takes the no-wait route (tests; a GPU shared in ways that starve
+    // the scan route's waits).  Read per call: it is a switch for a running process too.
+    if (!no_wait && !d_in2 && !indexed && !unsegmented) {
+        const char *f = std::getenv("WAH_FORCE_FALLBACK");
+        no_wait = f && f[0] == '1';
+    }
+    if (no_wait && (d_in2 || indexed || unsegmented)) {
+        set_err("WAH_NO_WAIT applies to the plain compress only");
+        return WAH_ERR_ARG;
+    }
     if (!d_out_words || !d_workspace || (n_words && ((!d_in && !indexed) || !d_out))) {
         set_err("null pointer");
         return WAH_ERR_ARG;
@@ -414,6 +425,11 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
         if (a.wave_segs > (uint32_t)wah::kCompressUnsegMaxWaveSegs) a.wave_segs = wah::kCompressUnsegMaxWaveSegs;
         a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
     }
+    if (no_wait) { // count / scan / place (compress_nowait_kernel): its own tile shape, the table in the second scan area
+        a.wave_segs = wah::compress_nowait_wave_segs();
+        a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
+        a.tile_counts = reinterpret_cast<uint64_t *>(ws + l.unseg_off);
+    }
     if (indexed) { // groups come from two indexed streams (bitop_tile_kernel): its own tile shape
         a.wave_segs = wah::kIndexedSegsPerWave;
         a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * wah::kIndexedSegsPerWave);
@@ -449,7 +465,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
         }
         if (check) e = wah::launch_bitop_check(check->info_a, check->info_b, check->ctrl_a, check->ctrl_b, check->groups, a.ctrl, s);
     }
-    if (e == hipSuccess) e = indexed ? wah::launch_bitop_tiles(a, *indexed, s) : wah::launch_compress(a, s);
+    if (e == hipSuccess) e = indexed ? wah::launch_bitop_tiles(a, *indexed, s) : no_wait ? wah::launch_compress_nowait(a, s) : wah::launch_compress(a, s);
     if (e != hipSuccess) {
         set_err("compress kernel launch", e);
         return WAH_ERR_HIP;
@@ -480,13 +496,13 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
 
 int wah_compress_device_ex(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
                            uint64_t *d_out_words, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream) {
-    if (flags & ~(unsigned)WAH_UNSEGMENTED) {
+    if (flags & ~(unsigned)(WAH_UNSEGMENTED | WAH_NO_WAIT)) {
         g_err[0] = 0;
         set_err("unknown flag");
         return WAH_ERR_ARG;
     }
     return compress_device_impl(d_in, nullptr, 0, nullptr, n_words, d_out, out_capacity_words, d_out_words, nullptr, d_workspace,
-                                workspace_bytes, stream, false, nullptr, nullptr, (flags & WAH_UNSEGMENTED) != 0);
+                                workspace_bytes, stream, false, nullptr, nullptr, (flags & WAH_UNSEGMENTED) != 0, (flags & WAH_NO_WAIT) != 0);
 }
 
 int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
@@ -1020,6 +1036,18 @@ uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *ou
     hc.mark();
     uint64_t c = 0;
     if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws, hc.cache.pinned, &c, 1); // status + size: one wait, no copy
+    if (rc == WAH_ERR_TIMEOUT) {
+        // A bounded wait inside the kernel expired: a workgroup this launch depended on did not get to run in time (a GPU
+        // shared in a way the arrival tickets do not cover, a preempted queue).  The no-wait route has no such
+        // dependency: three launches, the bitmap read twice, the same stream.
+        std::fprintf(stderr, "wah: compress: in-kernel wait expired, taking the no-wait route\n");
+        host_result[0] = 0;
+        rc = compress_device_impl(static_cast<uint32_t *>(d_in), nullptr, 0, nullptr, n_words, static_cast<uint32_t *>(d_out), cap, d_cnt,
+                                  nullptr, d_ws, ws_bytes, nullptr, false, host_result, nullptr, false, true);
+        if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws, hc.cache.pinned, &c, 1);
+        // (the abandoned launch left its tickets and its epoch half way: the next call starts from a fresh workspace)
+        if (rc == WAH_OK && wah_workspace_init_device(d_ws, ws_bytes, nullptr) != WAH_OK) rc = WAH_ERR_HIP;
+    }
     if (rc != WAH_OK) {
         std::fprintf(stderr, "wah: compress failed: %s\n", g_err);
         return nullptr;

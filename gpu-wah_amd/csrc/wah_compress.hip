@@ -462,7 +462,13 @@ struct IndexedSource {
 // kWaveSegs: segments a wavefront compresses one after the other (the tile = kTileWaves x kWaveSegs segments).  Large
 // bitmaps take 5: a wave's four idle stretches (first load, barrier, offset, store drain) are paid once per five
 // segments, and 16 waves per CU keep 80 segments in flight.  Small bitmaps take 1 or 2: more, shorter tiles.
-template <class Source, u32 kWaveSegs>
+//
+// kMode: kTileScan is the kernel described above.  kTileCount and kTilePlace are the two halves of the NO-WAIT route
+// (wah_compress_device_ex, WAH_NO_WAIT; include/wah.h): three launches in which no workgroup ever waits for another --
+// count (pass 1 only: the tile's word count to a table), tile_offsets_kernel (exclusive scan of the table), place
+// (the whole tile again, its offset out of the table).  The bitmap is read twice; tile = blockIdx, no ticket, no epoch.
+enum : int { kTileScan = 0, kTileCount = 1, kTilePlace = 2 };
+template <class Source, u32 kWaveSegs, int kMode = kTileScan>
 __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source &src) {
     __shared__ __attribute__((aligned(16))) u32 s_out[kTileWaves][kOutWords];
     __shared__ __attribute__((aligned(16))) unsigned short s_pos[kTileWaves][kPosEntries];
@@ -473,7 +479,7 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
-    const u32 tile = draw_tile(a.ctrl, &s_tile);
+    const u32 tile = kMode == kTileScan ? draw_tile(a.ctrl, &s_tile) : blockIdx.x;
     const u32 seg0 = (tile * kTileWaves + wave) * kWaveSegs; // this wave's segments: seg0 .. seg0 + kWaveSegs - 1
 #ifdef WAH_DIAG
     u64 dg_t[8];
@@ -485,10 +491,16 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
 #endif
 
     // ---- launch epoch (wah_device.hpp): the same value for every workgroup of the launch --------------------------------
-    const LaunchEpoch le = launch_epoch_begin(a.ctrl, tile, a.gen_desc, a.scan_words, a.keep_error);
-    if (le.bad) {
-        if (tile == a.n_tiles - 1 && threadIdx.x == 0) *a.out_words = 0;
-        return;
+    LaunchEpoch le = {};
+    if (kMode == kTileScan) {
+        le = launch_epoch_begin(a.ctrl, tile, a.gen_desc, a.scan_words, a.keep_error);
+        if (le.bad) {
+            if (tile == a.n_tiles - 1 && threadIdx.x == 0) *a.out_words = 0;
+            return;
+        }
+    } else if (kMode == kTileCount && tile == 0 && threadIdx.x == 0 && !a.keep_error) {
+        // a new launch: forget the previous one's status (nothing of this route raises an error before tile_offsets_kernel)
+        __hip_atomic_store(a.ctrl + kCtlError, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const u32 epoch = le.epoch;
 
@@ -537,12 +549,18 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
         const u32 incl = wave_scan_incl32(mine);
         if (lane < kTileWaves) s_prefix[lane] = incl - mine;
         total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        if (kMode == kTileCount) {
+            if (lane == 0) a.tile_counts[tile] = total;
+        } else if (kMode == kTilePlace) {
+            if (lane == 0) s_base = a.tile_counts[tile]; // (an offset by now: tile_offsets_kernel)
+        } else {
         if (lane == 0)
             __hip_atomic_store(block + (g.row - g.row0) * kRowTiles + g.idx, (epoch << kCountBits) | total, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         // One round trip of three loads per lane, issued now that the count is out and collected after pass 2: by
         // then the tiles dispatched before this one have normally published theirs.
         scan_issue(a, g, lane, true, g.has_prev, true, poll);
+        }
 #ifdef WAH_DIAG
         if (a.tune == 77u) { // time line mode: how long does the sweep itself take?
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -550,6 +568,8 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
         }
 #endif
     }
+
+    if (kMode == kTileCount) return;
 
     // ---- pass 2 of all the wave's segments: compaction in LDS, final words into registers -------------------------------------
 #pragma unroll
@@ -566,7 +586,7 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
     }
 
     DG(6);
-    if (wave == 0) {
+    if (kMode == kTileScan && wave == 0) {
         // ---- the tile's offset ---------------------------------------------------------------------------------------
         // If a few entries of the sweep are still missing (the nearest predecessors), only their lanes read again.  If
         // many are (a tile of an XCD that runs ahead of the others), the wave does NOT sweep again and again -- hundreds
@@ -1103,6 +1123,48 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
     compress_tile_body<BitmapSource<kPair, kAligned>, kWaveSegs>(a, src);
 }
 
+// ---- the no-wait route (kTileCount / kTilePlace above): two segments per wave, whatever the size of the bitmap ------
+constexpr u32 kNoWaitWaveSegs = 2;
+template <bool kAligned, int kMode>
+__global__ __launch_bounds__(kTileWaves * 64, 6) void compress_nowait_kernel(const CompressArgs a) {
+    BitmapSource<false, kAligned> src;
+    compress_tile_body<BitmapSource<false, kAligned>, kNoWaitWaveSegs, kMode>(a, src);
+}
+
+// counts of the tiles -> where every tile's words start (exclusive scan, in place), + everything the last tile of the
+// scan route leaves behind: C, the index's last entry, the capacity check, the host's copy of the result.  One workgroup:
+// the table has one entry per 16 segments (64 KB of bitmap), a 1 GiB bitmap has 17 000 of them.
+__global__ __launch_bounds__(1024) void tile_offsets_kernel(const CompressArgs a) {
+    __shared__ u64 s_wave[16];
+    __shared__ u64 s_carry;
+    const u32 lane = lane_id(), wave = wave_id();
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u32 t0 = 0; t0 < a.n_tiles; t0 += 1024u) {
+        const u32 t = t0 + threadIdx.x;
+        const u64 mine = t < a.n_tiles ? a.tile_counts[t] : 0ull;
+        const u64 incl = wave_scan_incl(mine, lane);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        u64 front = s_carry;
+        for (u32 w = 0; w < wave; ++w) front += s_wave[w];
+        if (t < a.n_tiles) a.tile_counts[t] = front + incl - mine;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = front + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const u64 end = s_carry;
+        *a.out_words = end;
+        if (a.seg_offsets) a.seg_offsets[a.n_segments] = end;
+        if (end > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+        if (a.host_result) {
+            a.host_result[1] = end;
+            a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
+        }
+    }
+}
+
 // wah_bitop_indexed_device: compress(A op B) straight from the two indexed streams.  Same tile kernel; the groups come
 // from the segment decoder instead of the bitmap.  Nothing of bitmap size is written or read: traffic = 4 C_A + 4 C_B
 // + 4 C_out (+ the indexes).  A range that is not exactly its segment (not a stream of compress() for this bitmap) is
@@ -1143,6 +1205,22 @@ static void launch_unseg(const CompressArgs &a, hipStream_t s) {
     case 2: hipLaunchKernelGGL((compress_unseg_kernel<kAligned, 2>), grid, block, 0, s, a); break;
     default: hipLaunchKernelGGL((compress_unseg_kernel<kAligned, 4>), grid, block, 0, s, a); break;
     }
+}
+
+uint32_t compress_nowait_wave_segs() { return kNoWaitWaveSegs; }
+
+hipError_t launch_compress_nowait(const CompressArgs &a, hipStream_t s) {
+    const dim3 grid(a.n_tiles), block(kTileWaves * 64);
+    if (a.fast_segments) {
+        hipLaunchKernelGGL((compress_nowait_kernel<true, kTileCount>), grid, block, 0, s, a);
+        hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL((compress_nowait_kernel<true, kTilePlace>), grid, block, 0, s, a);
+    } else {
+        hipLaunchKernelGGL((compress_nowait_kernel<false, kTileCount>), grid, block, 0, s, a);
+        hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL((compress_nowait_kernel<false, kTilePlace>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {

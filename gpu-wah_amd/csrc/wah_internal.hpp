@@ -85,6 +85,7 @@ struct CompressArgs {
     uint32_t *ctrl;        // kCtlWords
     uint32_t *gen_desc;    // scan area: blocks of kScanBlockWords (see compress_tile_kernel)
     uint32_t *unseg_desc;  // non-null: unsegmented mode, its scan area: blocks of kUnsegBlockWords (compress_unseg_kernel)
+    uint64_t *tile_counts; // no-wait route only: one entry per tile, its word count, then where its words start
     uint64_t scan_words;   // 32-bit words of the whole scan area
     int keep_error;        // 1: the control block was cleared by the caller and may already hold an upstream error
     uint64_t *host_result; // optional, page-locked HOST memory: [0] = 1 | error bits << 32, [1] = C, written by the last tile
@@ -162,6 +163,8 @@ struct PairCheck {
 
 // launchers (wah_compress.hip, wah_decode.hip, wah_aux.hip)
 hipError_t launch_compress(const CompressArgs &a, hipStream_t s); // pair mode when a.in2 != nullptr
+hipError_t launch_compress_nowait(const CompressArgs &a, hipStream_t s); // count, scan, place: nobody waits for anybody
+uint32_t compress_nowait_wave_segs();
 hipError_t launch_bitop_check(const uint64_t *info_a, const uint64_t *info_b, const uint32_t *ctrl_a, const uint32_t *ctrl_b, uint64_t groups,
                               uint32_t *ctrl, hipStream_t s);
 hipError_t launch_decode_sums(const ScanArgs &a, hipStream_t s);

@@ -117,6 +117,15 @@ int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out,
  * decodes to the same bitmap with wah_decompress*; it is not what the reference's encoder emits and has no segment
  * index. */
 #define WAH_UNSEGMENTED 1u
+/* WAH_NO_WAIT: the same stream as wah_compress_device by a route in which no workgroup ever waits for another: three
+ * launches -- count (every tile's word count to a table), one exclusive scan of the table, place (every tile again,
+ * its words to their place) -- and the bitmap is read twice (about 1.6 x the time).  The one-launch kernel resolves its
+ * offsets with bounded in-kernel waits on workgroups that started earlier (reference: thrust::exclusive_scan between two
+ * kernels, compress.cu:129-166); should such a wait ever expire the launch reports WAH_ERR_TIMEOUT, and this is the
+ * route to take instead: compress() does so by itself, a caller of the device API passes the flag (or sets
+ * WAH_FORCE_FALLBACK=1 in the environment, which sends every plain compress launch this way).  Not combinable with
+ * WAH_UNSEGMENTED.  After a WAH_ERR_TIMEOUT the workspace must be initialised again (wah_workspace_init_device). */
+#define WAH_NO_WAIT 2u
 int wah_compress_device_ex(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
                            uint64_t *d_out_words, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream);
 

@@ -403,6 +403,58 @@ def test_unsegmented_encoder_mode(wah, oracle):
                                             comp.workspace.data_ptr(), comp.ws_bytes, None) == -1
 
 
+# ---------------------------------------------------------------- the route on which nobody waits for anybody
+def test_no_wait_route(wah, oracle, monkeypatch):
+    """WAH_NO_WAIT / WAH_FORCE_FALLBACK=1: count, scan, place -- three launches, no in-kernel wait -- give the stream of the
+    one-launch kernel bit for bit: tails, several tiles, a table longer than one scan round, the index, the host entry
+    point, and the same workspace serving both routes in turn."""
+    import torch
+
+    sizes = (1, 31, 992, 992 * 16 + 5, 992 * 700 + 13, 992 * 40000 + 1)  # 40 000 segments: 2 500 tiles, three scan rounds
+    for n in sizes:
+        for seed, p in ((3, 0.01), (4, 0.5)):
+            data = oracle.gen_uniform(n, seed, p)
+            want = oracle.compress(data)
+            comp = wah.DeviceCompressor(n, no_wait=True)
+            comp.run(_dev(data))
+            assert np.array_equal(_host(comp.result()), want), (n, p)
+            del comp
+    data = oracle.gen_clustered(992 * 3000 + 17, 99)
+    want = oracle.compress(data)
+    d = _dev(data)
+    # one workspace, both routes in turn (the table lives in the unsegmented mode's scan area and must not disturb it)
+    normal = wah.DeviceCompressor(len(data))
+    normal.run(d)
+    assert np.array_equal(_host(normal.result()), want)
+    lib = wah.lib()
+    for flags in (2, 0, 1, 2, 0):
+        rc = lib.wah_compress_device_ex(d.data_ptr(), len(data), normal.out.data_ptr(), normal.capacity, normal.count.data_ptr(), flags,
+                                        normal.workspace.data_ptr(), normal.ws_bytes, None)
+        assert rc == 0
+        got = _host(normal.result())
+        assert np.array_equal(got, want if flags != 1 else _py_merge_fills(want)), flags
+    # not combinable with the unsegmented mode
+    assert lib.wah_compress_device_ex(d.data_ptr(), len(data), normal.out.data_ptr(), normal.capacity, normal.count.data_ptr(), 3,
+                                      normal.workspace.data_ptr(), normal.ws_bytes, None) == -1
+    # an output capacity below C is reported, nothing is written past it
+    guard = torch.full((len(data),), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    assert lib.wah_compress_device_ex(d.data_ptr(), len(data), guard.data_ptr(), 100, normal.count.data_ptr(), 2,
+                                      normal.workspace.data_ptr(), normal.ws_bytes, None) == 0
+    assert lib.wah_compress_status(normal.workspace.data_ptr(), None) == -4
+    assert bool((guard[100:] == 0x5A5A5A5A).all())
+    # the environment switch sends every plain compress launch this way: device API with the index, host entry point
+    monkeypatch.setenv("WAH_FORCE_FALLBACK", "1")
+    indexed = wah.DeviceCompressor(len(data), indexed=True)
+    indexed.run(d)
+    assert np.array_equal(_host(indexed.result()), want)
+    offs = indexed.seg_offsets.cpu().numpy()
+    assert offs[0] == 0 and offs[-1] == len(want) and bool(np.all(np.diff(offs) >= 1))
+    assert np.array_equal(wah.compress(data), want)
+    monkeypatch.delenv("WAH_FORCE_FALLBACK")
+    normal.run(d)
+    assert np.array_equal(_host(normal.result()), want)
+
+
 # ---------------------------------------------------------------- bitwise operations on compressed bitmaps
 def test_bitops_on_compressed_bitmaps(wah, oracle):
     """wah_bitop_device(op, A, B) == compress(decompress(A) op decompress(B)), for whole-segment and ragged lengths."""
