@@ -74,6 +74,8 @@ def parse(argv=None):
     ap.add_argument("--columns", type=int, default=None, help=f"columns workload: total number of columns (default {COLUMNS_TOTAL})")
     ap.add_argument("--columns-per-launch", type=int, default=COLUMNS_PER_LAUNCH)
     ap.add_argument("--per-column-launches", action="store_true", help="columns workload: one launch per column")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="columns workload with --per-column-launches: HIP streams the launches are spread over (one workspace each)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="size of the CPU-baseline sample (default: the whole 1 GiB bitmap, about 10 s of host work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1337)
@@ -250,29 +252,42 @@ def run_rank(args):
             # all of the rank's columns stay resident: one [columns, n] matrix, generated once
             matrix = wah.columns.make_column_matrix(wah, specs, dev) if specs else None
             widest = max((len(b) for b in batches), default=1)
-            comp = wah.DeviceCompressor(widest * n if batched else n, device=dev, indexed=batched)
-            sizes = []
+            # per-column launches go round robin over a few streams, each with its own compressor (output buffer +
+            # workspace): the tail of one launch overlaps the start of the next ("just per-GPU streams", north_star)
+            n_streams = max(1, min(args.streams, len(batches))) if not batched else 1
+            comps = [wah.DeviceCompressor(widest * n if batched else n, device=dev, indexed=batched) for _ in range(n_streams)]
+            streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
+            sizes = torch.zeros(max(len(batches), 1), dtype=torch.int64, device=dev) # C of every launch, written by the kernels
 
             def step():
                 row = 0
-                sizes.clear()
-                for b in batches:
+                main = torch.cuda.current_stream(dev)
+                for st in streams:
+                    if st is not None:
+                        st.wait_stream(main)
+                for i, b in enumerate(batches):
                     rows = matrix[row:row + len(b)]
+                    comp, st = comps[i % n_streams], streams[i % n_streams]
                     if batched:
                         # ONE launch per batch: whole 992-word segments, so the result is the columns' streams back to
                         # back; the segment index gives the column boundaries
-                        comp.run(rows.view(-1), n_words=rows.numel())
+                        comp.run(rows.view(-1), n_words=rows.numel(), count=sizes[i:i + 1])
                     else:
-                        comp.run(rows[0])
-                    sizes.append(comp.count.clone())
+                        comp.run(rows[0], stream=st, count=sizes[i:i + 1])
                     row += len(b)
+                for st in streams:
+                    if st is not None:
+                        main.wait_stream(st)
 
             step()
-            comp.status()
-            c_words_rank = float(sum(int(s.item()) for s in sizes))
+            torch.cuda.synchronize(dev)
+            for comp in comps:
+                comp.status()
+            c_words_rank = float(sizes.sum().item())
         elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
         if not cpu_only:
-            comp.status()
+            for comp in comps:
+                comp.status()
         stats = torch.tensor([4.0 * n * len(mine), c_words_rank], dtype=torch.float64)
         if dist is not None:
             dist.all_reduce(stats)
@@ -286,6 +301,7 @@ def run_rank(args):
                 "config": {"workload": desc, "words_per_column": n, "columns": n_columns,
                            "columns_per_gpu": len(mine), "seed": args.seed, "launches_per_step": len(batches),
                            "columns_per_launch": max((len(b) for b in batches), default=0),
+                           "streams": 1 if cpu_only else n_streams,
                            "parallelism": f"column-shard x{world}, no collective"},
                 "compression_ratio_C_over_N": round(c_words_job * 4.0 / in_bytes_job, 6) if in_bytes_job else None,
             }

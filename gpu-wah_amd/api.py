@@ -225,23 +225,31 @@ class DeviceCompressor:
         n_seg = (self.capacity + 1023) // 1024
         self.seg_offsets = torch.zeros(n_seg + 1, dtype=torch.int64, device=device) if indexed else None
 
-    def run(self, d_in, n_words=None, stream=None):
-        """Enqueue one compress pass; returns nothing (read .count / .out after synchronising)."""
+    def run(self, d_in, n_words=None, stream=None, count=None):
+        """Enqueue one compress pass; returns nothing (read .count / .out after synchronising).  count: another
+        one-element int64 device tensor to receive C instead of .count (a slot per column, say)."""
         torch = _torch()
         _as_words(torch, d_in)
         n = self.n_words if n_words is None else int(n_words)
         if n > self.n_words or n > d_in.numel():
             raise WahError("input larger than this compressor was sized for")
         sp = _stream_ptr(torch, stream)
+        if count is not None:
+            if count.dtype != torch.int64 or count.numel() != 1 or not count.is_cuda:
+                raise WahError("count must be a one-element int64 device tensor")
+            return self._run(d_in, n, sp, count.data_ptr())
+        return self._run(d_in, n, sp, self.count.data_ptr())
+
+    def _run(self, d_in, n, sp, count_ptr):
         if self.unsegmented or self.no_wait:
-            rc = lib().wah_compress_device_ex(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, self.count.data_ptr(),
+            rc = lib().wah_compress_device_ex(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, count_ptr,
                                               1 if self.unsegmented else 2, self.workspace.data_ptr(), self.ws_bytes, sp)
         elif self.seg_offsets is None:
-            rc = lib().wah_compress_device(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, self.count.data_ptr(),
+            rc = lib().wah_compress_device(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, count_ptr,
                                            self.workspace.data_ptr(), self.ws_bytes, sp)
         else:
             rc = lib().wah_compress_device_indexed(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity,
-                                                   self.count.data_ptr(), self.seg_offsets.data_ptr(),
+                                                   count_ptr, self.seg_offsets.data_ptr(),
                                                    self.workspace.data_ptr(), self.ws_bytes, sp)
         _check(rc, "wah_compress_device")
 
