@@ -369,6 +369,37 @@ def run_rank(args):
     comp_isolated = ce[0].elapsed_time(ce[1]) / 10
     comp.status()
 
+    # throughput with TWO round trips in flight (a side measurement, never `value`): a second compressor / decompressor
+    # pair on a second stream works on the same bitmap, so the tail of one launch overlaps the start of the next
+    # (independent requests of a serving system; `value` stays the one-at-a-time rate of the contract)
+    two_in_flight = None
+    if world == 1:
+        comp2 = wah.DeviceCompressor(n, device=dev)
+        dec2 = wah.DeviceDecompressor(c_words, n + 1, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+
+        def pair_step():
+            side.wait_stream(main)
+            comp.run(d_in)
+            dec.run(comp.out, c_words)
+            comp2.run(d_in, stream=side)
+            dec2.run(comp2.out, c_words, stream=side)
+            main.wait_stream(side)
+
+        pair_step()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(dec2.result()[:n], d_in), "round trip mismatch (second stream)"
+        pairs = max(args.steps // 2, 2)
+        t0 = time.perf_counter()
+        for _ in range(pairs):
+            pair_step()
+        torch.cuda.synchronize(dev)
+        two_in_flight = 2 * pairs * 4.0 * n / (time.perf_counter() - t0) / 1e9
+        comp2.status()
+        dec2.status()
+        del comp2, dec2
+
     # on-box copy ceiling: 16 B/lane copy of the same bitmap (read + write)
     scratch = torch.empty_like(d_in)
     for _ in range(2):
@@ -422,6 +453,7 @@ def run_rank(args):
             "compress_ms": {"avg": round(comp_avg, 4), "min": round(comp_ms[0], 4), "median": round(comp_ms[len(comp_ms) // 2], 4)},
             "decompress_ms": {"avg": round(dec_avg, 4), "min": round(dec_ms[0], 4), "median": round(dec_ms[len(dec_ms) // 2], 4)},
             "copy_ceiling_GBps": round(copy_gbps, 1),
+            "two_round_trips_in_flight_GBps": round(two_in_flight, 1) if two_in_flight else None,
             "roofline": {"kernel": "compress_tile_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": tr.get("compress_bytes_per_launch"), "traffic_measured_in_run": False,
