@@ -1108,28 +1108,49 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
 
     // phase 2: device work (decompress.cu:56-122): size scan, allocate, scan + expand
     hc.start();
-    uint64_t *const host_result = reinterpret_cast<uint64_t *>(hc.cache.pinned) + 4; // behind the copy's landing area
-    host_result[0] = 0;
-    int rc = decode_common(static_cast<uint32_t *>(d_comp), c_words, nullptr, 0, d_info, d_ws0, ws0, nullptr, true, false, false,
-                           c_words ? host_result : nullptr);
     uint64_t info[2] = {0, 0};
-    if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws0, hc.cache.pinned, info, 2); // status + sizes: one wait, no copy
-    if (rc != WAH_OK) {
-        std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
-        return nullptr;
+    void *d_out = nullptr;
+    int rc = WAH_OK;
+    bool expanded = false;
+    // An output buffer kept from an earlier call (the reference's callers decompress in loops, source.cpp:70): expand
+    // right behind the scan, into what is there -- the expand kernel compares the decoded size with the capacity on the
+    // device and writes nothing if it does not fit.  One host round trip for the whole phase instead of two.
+    const size_t kept_words = hc.keep && hc.cache.buf[0] ? hc.cache.cap[0] / sizeof(uint32_t) : 0;
+    if (c_words && kept_words) {
+        rc = decode_common(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(hc.cache.buf[0]), kept_words, d_info, d_ws0,
+                           ws0, nullptr, true, true);
+        hc.mark();
+        if (rc == WAH_OK) rc = read_status_packed(d_ws0, hc.cache.pinned, info, 2); // status + sizes in one copy
+        if (rc == WAH_OK) {
+            d_out = hc.cache.buf[0];
+            expanded = true;
+        } else if (rc != WAH_ERR_CAPACITY) {
+            std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
+            return nullptr;
+        } // (too small: by the book below)
+    }
+    if (!expanded) {
+        uint64_t *const host_result = reinterpret_cast<uint64_t *>(hc.cache.pinned) + 4; // behind the copy's landing area
+        host_result[0] = 0;
+        rc = decode_common(static_cast<uint32_t *>(d_comp), c_words, nullptr, 0, d_info, d_ws0, ws0, nullptr, true, false, false,
+                           c_words ? host_result : nullptr);
+        if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws0, hc.cache.pinned, info, 2); // status + sizes: one wait, no copy
+        if (rc != WAH_OK) {
+            std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
+            return nullptr;
+        }
+        if (!hc.alloc(0, &d_out, info[0] * sizeof(uint32_t), "space for the result")) return nullptr;
+        // the tile bases of the scan are still in the workspace: expand only
+        rc = wah_decompress_expand_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(d_out), info[0], d_info,
+                                          d_ws0, ws0, nullptr);
+        hc.mark();
+        if (rc == WAH_OK) rc = read_status_packed(d_ws0, hc.cache.pinned, nullptr, 0);
+        if (rc != WAH_OK) {
+            std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
+            return nullptr;
+        }
     }
     const uint64_t n_out = info[0], groups = info[1];
-    void *d_out = nullptr;
-    if (!hc.alloc(0, &d_out, n_out * sizeof(uint32_t), "space for the result")) return nullptr;
-    // the tile bases of the scan are still in the workspace: expand only
-    rc = wah_decompress_expand_device(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(d_out), n_out, d_info,
-                                      d_ws0, ws0, nullptr);
-    hc.mark();
-    if (rc == WAH_OK) rc = read_status_packed(d_ws0, hc.cache.pinned, nullptr, 0);
-    if (rc != WAH_OK) {
-        std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
-        return nullptr;
-    }
     t_dev = hc.since_mark();
 
     // phase 3: D2H + free (decompress.cu:124-131).  The reference hands back a buffer of G words
