@@ -74,6 +74,9 @@ def parse(argv=None):
     ap.add_argument("--columns", type=int, default=None, help=f"columns workload: total number of columns (default {COLUMNS_TOTAL})")
     ap.add_argument("--columns-per-launch", type=int, default=COLUMNS_PER_LAUNCH)
     ap.add_argument("--per-column-launches", action="store_true", help="columns workload: one launch per column")
+    ap.add_argument("--two-in-flight", action="store_true",
+                    help="round-trip workloads: also measure the throughput with two round trips in flight on two streams "
+                         "(a side field; off by default so that a kernel trace of the default command holds one launch at a time)")
     ap.add_argument("--streams", type=int, default=2,
                     help="columns workload with --per-column-launches: HIP streams the launches are spread over (one workspace each)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="size of the CPU-baseline sample (default: the whole 1 GiB bitmap, about 10 s of host work)")
@@ -373,7 +376,7 @@ def run_rank(args):
     # pair on a second stream works on the same bitmap, so the tail of one launch overlaps the start of the next
     # (independent requests of a serving system; `value` stays the one-at-a-time rate of the contract)
     two_in_flight = None
-    if world == 1:
+    if world == 1 and args.two_in_flight:
         comp2 = wah.DeviceCompressor(n, device=dev)
         dec2 = wah.DeviceDecompressor(c_words, n + 1, device=dev)
         side = torch.cuda.Stream(device=dev)
