@@ -124,7 +124,8 @@ int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out,
  * kernels, compress.cu:129-166); should such a wait ever expire the launch reports WAH_ERR_TIMEOUT, and this is the
  * route to take instead: compress() does so by itself, a caller of the device API passes the flag (or sets
  * WAH_FORCE_FALLBACK=1 in the environment, which sends every plain compress launch this way).  Not combinable with
- * WAH_UNSEGMENTED.  After a WAH_ERR_TIMEOUT the workspace must be initialised again (wah_workspace_init_device). */
+ * WAH_UNSEGMENTED.  The route itself reads nothing of the workspace's earlier content; before the one-launch kernel is used
+ * again after a WAH_ERR_TIMEOUT the workspace must be initialised again (wah_workspace_init_device). */
 #define WAH_NO_WAIT 2u
 int wah_compress_device_ex(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out, uint64_t out_capacity_words,
                            uint64_t *d_out_words, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream);
