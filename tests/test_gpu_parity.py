@@ -403,6 +403,53 @@ def test_unsegmented_encoder_mode(wah, oracle):
                                             comp.workspace.data_ptr(), comp.ws_bytes, None) == -1
 
 
+# ---------------------------------------------------------------- host decompress: kept output buffer; count slots, streams
+def test_host_decompress_kept_output_buffer(wah, oracle):
+    """decompress() expands right behind its scan into the output buffer kept from the call before, and falls back to
+    scan -> allocate -> expand when that buffer is too small: small, large, small again, then an empty stream."""
+    for n, p in ((992 * 3, 0.3), (992 * 4000 + 5, 0.01), (31, 0.5), (992 * 900, 2.0**-9), (992 * 4000 + 5, 0.5), (1, 0.5)):
+        data = oracle.gen_uniform(n, n % 97, p)
+        comp = oracle.compress(data)
+        back = wah.decompress(comp)
+        assert np.array_equal(back, oracle.decompress(comp)), (n, p)
+    assert len(wah.decompress(np.zeros(0, np.uint32))) == 0
+    # a malformed stream (groups beyond 2^47) is still refused on the short cut
+    with pytest.raises(wah.WahError):
+        wah.decompress(np.full(1 << 18, 0xBFFFFFFF, np.uint32))
+
+
+def test_compress_count_slots_and_streams(wah, oracle):
+    """DeviceCompressor.run(count=slot, stream=s): launches of several compressors on several streams, every launch
+    writing its C into its own slot (the columns workload of bench.py)."""
+    import torch
+
+    n = 992 * 257 + 3
+    cols = [oracle.gen_uniform(n, 100 + i, (0.5, 0.01, 2.0**-8)[i % 3]) for i in range(6)]
+    d_cols = [_dev(c) for c in cols]
+    comps = [wah.DeviceCompressor(n) for _ in range(2)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    slots = torch.zeros(len(cols), dtype=torch.int64, device="cuda")
+    main = torch.cuda.current_stream()
+    results = []
+    for i, d in enumerate(d_cols):
+        c, st = comps[i % 2], streams[i % 2]
+        st.wait_stream(main)
+        c.run(d, stream=st, count=slots[i:i + 1])
+        with torch.cuda.stream(st):
+            results.append(c.out[: c.capacity].clone())  # (the compressor's buffer is reused by its next column)
+    for st in streams:
+        main.wait_stream(st)
+    torch.cuda.synchronize()
+    for c in comps:
+        c.status()
+    for i, col in enumerate(cols):
+        want = oracle.compress(col)
+        assert int(slots[i].item()) == len(want)
+        assert np.array_equal(_host(results[i][: len(want)]), want), i
+    with pytest.raises(wah.WahError):
+        comps[0].run(d_cols[0], count=torch.zeros(2, dtype=torch.int64, device="cuda"))
+
+
 # ---------------------------------------------------------------- the route on which nobody waits for anybody
 def test_no_wait_route(wah, oracle, monkeypatch):
     """WAH_NO_WAIT / WAH_FORCE_FALLBACK=1: count, scan, place -- three launches, no in-kernel wait -- give the stream of the
