@@ -78,7 +78,7 @@ def parse(argv=None):
                     help="round-trip workloads: also measure the throughput with two round trips in flight on two streams "
                          "(a side field; off by default so that a kernel trace of the default command holds one launch at a time)")
     ap.add_argument("--streams", type=int, default=2,
-                    help="columns workload with --per-column-launches: HIP streams the launches are spread over (one workspace each)")
+                    help="columns workload: HIP streams the launches are spread over (one compressor = output buffer + workspace each)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="size of the CPU-baseline sample (default: the whole 1 GiB bitmap, about 10 s of host work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1337)
@@ -173,8 +173,14 @@ def cpu_baseline(kind, param, sample_mib, seed):
     data = oracle.gen_uniform(n, seed, param) if kind == "uniform" else oracle.gen_clustered(n, seed, param)
     tc, td, _ = oracle.time_round_trip(data, threads=1, reps=2)
     nbytes = 4.0 * n
+    cpu_model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((line.split(":", 1)[1].strip() for line in f if line.startswith("model name")), None)
+    except OSError:
+        pass
     res = {
-        "value": round(nbytes / (tc + td) / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+        "value": round(nbytes / (tc + td) / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port", "cpu_model": cpu_model,
         "sample": f"{sample_mib} MiB of the same {kind} bitmap (seed {seed}), serial C oracle, compress+decompress, best of 2",
         "compress_GBps": round(nbytes / tc / 1e9, 4), "decompress_GBps": round(nbytes / td / 1e9, 4),
     }
@@ -255,9 +261,9 @@ def run_rank(args):
             # all of the rank's columns stay resident: one [columns, n] matrix, generated once
             matrix = wah.columns.make_column_matrix(wah, specs, dev) if specs else None
             widest = max((len(b) for b in batches), default=1)
-            # per-column launches go round robin over a few streams, each with its own compressor (output buffer +
-            # workspace): the tail of one launch overlaps the start of the next ("just per-GPU streams", north_star)
-            n_streams = max(1, min(args.streams, len(batches))) if not batched else 1
+            # the launches go round robin over a few streams, each with its own compressor (output buffer + workspace):
+            # the tail of one launch overlaps the start of the next ("just per-GPU streams", north_star)
+            n_streams = max(1, min(args.streams, len(batches)))
             comps = [wah.DeviceCompressor(widest * n if batched else n, device=dev, indexed=batched) for _ in range(n_streams)]
             streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
             sizes = torch.zeros(max(len(batches), 1), dtype=torch.int64, device=dev) # C of every launch, written by the kernels
@@ -274,7 +280,7 @@ def run_rank(args):
                     if batched:
                         # ONE launch per batch: whole 992-word segments, so the result is the columns' streams back to
                         # back; the segment index gives the column boundaries
-                        comp.run(rows.view(-1), n_words=rows.numel(), count=sizes[i:i + 1])
+                        comp.run(rows.view(-1), n_words=rows.numel(), stream=st, count=sizes[i:i + 1])
                     else:
                         comp.run(rows[0], stream=st, count=sizes[i:i + 1])
                     row += len(b)
