@@ -554,12 +554,12 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
         } else if (kMode == kTilePlace) {
             if (lane == 0) s_base = a.tile_counts[tile]; // (an offset by now: tile_offsets_kernel)
         } else {
-        if (lane == 0)
-            __hip_atomic_store(block + (g.row - g.row0) * kRowTiles + g.idx, (epoch << kCountBits) | total, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        // One round trip of three loads per lane, issued now that the count is out and collected after pass 2: by
-        // then the tiles dispatched before this one have normally published theirs.
-        scan_issue(a, g, lane, true, g.has_prev, true, poll);
+            if (lane == 0)
+                __hip_atomic_store(block + (g.row - g.row0) * kRowTiles + g.idx, (epoch << kCountBits) | total, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            // One round trip of three loads per lane, issued now that the count is out and collected after pass 2: by
+            // then the tiles dispatched before this one have normally published theirs.
+            scan_issue(a, g, lane, true, g.has_prev, true, poll);
         }
 #ifdef WAH_DIAG
         if (a.tune == 77u) { // time line mode: how long does the sweep itself take?
