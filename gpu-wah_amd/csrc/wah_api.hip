@@ -420,6 +420,15 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     a.n_tiles = (uint32_t)l.n_tiles;
     a.wave_segs = l.wave_segs;
     a.unseg_desc = nullptr;
+    a.pair_layout = 0;
+    if (!d_in2 && !indexed && !unsegmented && !no_wait) { // the plain compress: pair-layout kernel, its own tile shape
+        const uint32_t pairs = wah::compress_wave_pairs(l.n_segments);
+        if (pairs) {
+            a.pair_layout = 1;
+            a.wave_segs = 2 * pairs;
+            a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
+        }
+    }
     if (unsegmented) { // fills cross the segment cut (compress_unseg_kernel): its own scan area, at most 4 segments per wave
         a.unseg_desc = reinterpret_cast<uint32_t *>(ws + l.unseg_off);
         if (a.wave_segs > (uint32_t)wah::kCompressUnsegMaxWaveSegs) a.wave_segs = wah::kCompressUnsegMaxWaveSegs;

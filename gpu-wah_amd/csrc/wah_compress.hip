@@ -253,14 +253,14 @@ __device__ __forceinline__ void classify_pass2(const SegGroups &g, SegEnds e, u3
 constexpr u32 kTileWaves = (u32)kCompressTileWaves;
 constexpr u32 kRowTiles = 256;             // granules per row: one 16-byte load per lane
 constexpr u32 kSuperRows = 64;             // rows per superrow: one 8-byte load per lane
-constexpr u32 kCountBits = 16;             // words of a tile <= 8 * 4 * 1024 (stored minus nothing: 2^15 fits 16 bits)
-constexpr u32 kCountMask = (1u << kCountBits) - 1u;
+constexpr u32 kGranuleCountBits = 16;             // words of a tile <= 8 * 4 * 1024 (stored minus nothing: 2^15 fits 16 bits)
+constexpr u32 kGranuleCountMask = (1u << kGranuleCountBits) - 1u;
 constexpr u32 kSlotShift = 48;             // u64 slots: value in the low 48 bits
 constexpr u64 kSlotMask = (1ull << kSlotShift) - 1ull;
-static_assert(kTileWaves * kCompressMaxWaveSegs * kSegGroups <= kCountMask, "tile count must fit the granule");
-static_assert(kEpochWrap < (1u << (32 - kCountBits)), "epochs must fit the granule");
+static_assert(kTileWaves * 6 * kSegGroups <= kGranuleCountMask, "tile count must fit the granule");
+static_assert(kEpochWrap < (1u << (32 - kGranuleCountBits)), "epochs must fit the granule");
 static_assert(kRowSlots == kSuperRows + 1, "slot layout");
-static_assert(kSlotShift - 32 == kCountBits, "the high half of a slot carries its epoch where a granule does");
+static_assert(kSlotShift - 32 == kGranuleCountBits, "the high half of a slot carries its epoch where a granule does");
 static_assert(kScanBlockWords >= kSuperRows * kRowTiles + 2 * kRowSlots && kScanSlotsAt == kSuperRows * kRowTiles, "scan block layout");
 
 constexpr u32 kDirectLanes = 16; // up to this many lanes with missing entries (the nearest ~64 predecessors) are simply read again
@@ -358,6 +358,134 @@ __device__ __forceinline__ void emit_regs(const CompressArgs &a, u64 base, u32 c
             for (int k = 0; k < 4; ++k) __builtin_amdgcn_raw_buffer_store_b32(out[4 * t + k], rsrc, off + 256u * (4 * t + k), 0, 0);
         }
     }
+}
+
+// Wave 0 of a tile, once the tile's count is out and its sweep issued (scan_issue): the tile's output offset, and what
+// the last tile of a row / of a superrow / of the launch leaves behind ("Row scan" above).  Returns the offset.
+__device__ __forceinline__ u64 tile_scan_resolve(const CompressArgs &a, const ScanGeom &g, u32 *const block, const LaunchEpoch &le, u32 tile,
+                                                 u32 total, u32 lane, TileScan &poll, u64 *dg_t, u32 *dg_polls, bool keep_ticket = false) {
+    const u32 epoch = le.epoch;
+    (void)dg_t;
+    (void)dg_polls;
+    // ---- the tile's offset ---------------------------------------------------------------------------------------
+    // If a few entries of the sweep are still missing (the nearest predecessors), only their lanes read again.  If
+    // many are (a tile of an XCD that runs ahead of the others), the wave does NOT sweep again and again -- hundreds
+    // of waiting tiles re-reading 2.5 KB each every microsecond is traffic of the order of the bitmap's: it spins on
+    // ONE word, the missing entry with the highest tile number, the one that will be published last, and sweeps
+    // again when that one is there.
+    bool need_a = true, need_b = g.has_prev, need_c = true;
+    u32 sum_a = 0, sum_b = 0;
+    u64 sum_c = 0;
+    u32 spins = 0;
+    for (;;) {
+        u32 bad_a = 0, bad_b = 0; // per lane: which of my four entries are missing
+        bool bad_c = false;
+        u64 ba = 0, bb = 0, bc = 0;
+        if (need_a) {
+            const u32 k0 = 4u * lane;
+            bad_a = ((k0 < g.idx && (poll.a.x >> kGranuleCountBits) != epoch) ? 1u : 0u) | ((k0 + 1u < g.idx && (poll.a.y >> kGranuleCountBits) != epoch) ? 2u : 0u) |
+                    ((k0 + 2u < g.idx && (poll.a.z >> kGranuleCountBits) != epoch) ? 4u : 0u) | ((k0 + 3u < g.idx && (poll.a.w >> kGranuleCountBits) != epoch) ? 8u : 0u);
+            ba = __ballot(bad_a != 0u);
+            if (ba == 0) {
+                // entries at and above my index lie behind the descriptor and read as zero
+                sum_a = uniform32(wave_sum32((poll.a.x & kGranuleCountMask) + (poll.a.y & kGranuleCountMask) + (poll.a.z & kGranuleCountMask) + (poll.a.w & kGranuleCountMask)));
+                need_a = false;
+                // my row is complete with me: its total is all that later superrow-mates need of it
+                if (g.idx == kRowTiles - 1u && lane == 0)
+                    __hip_atomic_store(reinterpret_cast<u64 *>(block + kScanSlotsAt) + 1u + (g.row - g.row0),
+                                       ((u64)epoch << kSlotShift) | ((u64)sum_a + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (need_b) {
+            bad_b = ((poll.b.x >> kGranuleCountBits) != epoch ? 1u : 0u) | ((poll.b.y >> kGranuleCountBits) != epoch ? 2u : 0u) |
+                    ((poll.b.z >> kGranuleCountBits) != epoch ? 4u : 0u) | ((poll.b.w >> kGranuleCountBits) != epoch ? 8u : 0u);
+            bb = __ballot(bad_b != 0u);
+            if (bb == 0) {
+                sum_b = uniform32(wave_sum32((poll.b.x & kGranuleCountMask) + (poll.b.y & kGranuleCountMask) + (poll.b.z & kGranuleCountMask) + (poll.b.w & kGranuleCountMask)));
+                need_b = false;
+            }
+        }
+        if (need_c) {
+            // slot 0 of superrow 0 is never written: nothing lies in front of the first tile
+            const bool wanted = lane < g.n_slots && !(g.sup == 0u && lane == 0u);
+            bad_c = wanted && (u32)(poll.c >> kSlotShift) != epoch;
+            bc = __ballot(bad_c);
+            if (bc == 0) {
+                sum_c = uniform64(wave_sum(wanted ? poll.c & kSlotMask : 0ull));
+                need_c = false;
+            }
+        }
+        if (!(need_a || need_b || need_c)) break;
+        if (++spins > kMaxSpins) {
+            if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
+            break;
+        }
+        const u32 n_bad = (u32)__builtin_popcountll(ba) + (u32)__builtin_popcountll(bb) + (u32)__builtin_popcountll(bc);
+        if (n_bad <= kDirectLanes) {
+            // a few stragglers among the nearest predecessors (the usual case): read just those lanes' entries again
+            __builtin_amdgcn_s_sleep(4);
+            if (need_a && bad_a != 0u) scan_issue(a, g, lane, true, false, false, poll);
+            if (need_b && bad_b != 0u) scan_issue(a, g, lane, false, true, false, poll);
+            if (need_c && bad_c) scan_issue(a, g, lane, false, false, true, poll);
+#ifdef WAH_DIAG
+            ++*dg_polls;
+#endif
+            continue;
+        }
+        // the word to wait for: {epoch, ...} in its top bits, whichever array it belongs to
+        const u32 *target;
+        if (need_a) {
+            const u32 hl = 63u - (u32)__builtin_clzll(ba);
+            const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_a, (int)hl);
+            target = block + (g.row - g.row0) * kRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
+        } else if (need_b) {
+            const u32 hl = 63u - (u32)__builtin_clzll(bb);
+            const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_b, (int)hl);
+            target = block + (g.row - 1u - g.row0) * kRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
+        } else {
+            const u32 hl = 63u - (u32)__builtin_clzll(bc);
+            target = block + kScanSlotsAt + 2u * hl + 1u; // high half of the slot
+        }
+        bool timed_out = false;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((__hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> kGranuleCountBits) == epoch) break;
+            if (++spins > kMaxSpins) {
+                timed_out = true;
+                break;
+            }
+        }
+        if (timed_out) {
+            if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
+            break;
+        }
+        scan_issue(a, g, lane, need_a, need_b, need_c, poll);
+#ifdef WAH_DIAG
+        ++*dg_polls;
+#endif
+    }
+#ifdef WAH_DIAG
+    dg_t[4] = __builtin_amdgcn_s_memrealtime();
+#endif
+    const u64 base = sum_c + sum_b + sum_a;
+    const u64 end = base + total;
+    if (lane == 0) {
+        if (g.idx == kRowTiles - 1u && g.row - g.row0 == kSuperRows - 1u) // last tile of a superrow
+            __hip_atomic_store(reinterpret_cast<u64 *>(a.gen_desc + (u64)(g.sup + 1u) * kScanBlockWords + kScanSlotsAt),
+                               ((u64)epoch << kSlotShift) | end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tile == a.n_tiles - 1) {
+            *a.out_words = end;
+            if (a.seg_offsets) a.seg_offsets[a.n_segments] = end;
+            if (end > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+            if (a.host_result) {
+                // every scan of the launch can complete now (this one needed all of them), so the error word is final
+                a.host_result[1] = end;
+                a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
+            }
+            launch_epoch_end(a.ctrl, le, keep_ticket); // every other tile has published, so it has read the epoch: advance it
+        }
+    }
+    return base;
 }
 
 // Where a wave's 31-bit groups come from -- the only thing that differs between compressing a bitmap and combining
@@ -555,7 +683,7 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
             if (lane == 0) s_base = a.tile_counts[tile]; // (an offset by now: tile_offsets_kernel)
         } else {
             if (lane == 0)
-                __hip_atomic_store(block + (g.row - g.row0) * kRowTiles + g.idx, (epoch << kCountBits) | total, __ATOMIC_RELAXED,
+                __hip_atomic_store(block + (g.row - g.row0) * kRowTiles + g.idx, (epoch << kGranuleCountBits) | total, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
             // One round trip of three loads per lane, issued now that the count is out and collected after pass 2: by
             // then the tiles dispatched before this one have normally published theirs.
@@ -587,123 +715,12 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
 
     DG(6);
     if (kMode == kTileScan && wave == 0) {
-        // ---- the tile's offset ---------------------------------------------------------------------------------------
-        // If a few entries of the sweep are still missing (the nearest predecessors), only their lanes read again.  If
-        // many are (a tile of an XCD that runs ahead of the others), the wave does NOT sweep again and again -- hundreds
-        // of waiting tiles re-reading 2.5 KB each every microsecond is traffic of the order of the bitmap's: it spins on
-        // ONE word, the missing entry with the highest tile number, the one that will be published last, and sweeps
-        // again when that one is there.
-        bool need_a = true, need_b = g.has_prev, need_c = true;
-        u32 sum_a = 0, sum_b = 0;
-        u64 sum_c = 0;
-        u32 spins = 0;
-        for (;;) {
-            u32 bad_a = 0, bad_b = 0; // per lane: which of my four entries are missing
-            bool bad_c = false;
-            u64 ba = 0, bb = 0, bc = 0;
-            if (need_a) {
-                const u32 k0 = 4u * lane;
-                bad_a = ((k0 < g.idx && (poll.a.x >> kCountBits) != epoch) ? 1u : 0u) | ((k0 + 1u < g.idx && (poll.a.y >> kCountBits) != epoch) ? 2u : 0u) |
-                        ((k0 + 2u < g.idx && (poll.a.z >> kCountBits) != epoch) ? 4u : 0u) | ((k0 + 3u < g.idx && (poll.a.w >> kCountBits) != epoch) ? 8u : 0u);
-                ba = __ballot(bad_a != 0u);
-                if (ba == 0) {
-                    // entries at and above my index lie behind the descriptor and read as zero
-                    sum_a = uniform32(wave_sum32((poll.a.x & kCountMask) + (poll.a.y & kCountMask) + (poll.a.z & kCountMask) + (poll.a.w & kCountMask)));
-                    need_a = false;
-                    // my row is complete with me: its total is all that later superrow-mates need of it
-                    if (g.idx == kRowTiles - 1u && lane == 0)
-                        __hip_atomic_store(reinterpret_cast<u64 *>(block + kScanSlotsAt) + 1u + (g.row - g.row0),
-                                           ((u64)epoch << kSlotShift) | ((u64)sum_a + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            if (need_b) {
-                bad_b = ((poll.b.x >> kCountBits) != epoch ? 1u : 0u) | ((poll.b.y >> kCountBits) != epoch ? 2u : 0u) |
-                        ((poll.b.z >> kCountBits) != epoch ? 4u : 0u) | ((poll.b.w >> kCountBits) != epoch ? 8u : 0u);
-                bb = __ballot(bad_b != 0u);
-                if (bb == 0) {
-                    sum_b = uniform32(wave_sum32((poll.b.x & kCountMask) + (poll.b.y & kCountMask) + (poll.b.z & kCountMask) + (poll.b.w & kCountMask)));
-                    need_b = false;
-                }
-            }
-            if (need_c) {
-                // slot 0 of superrow 0 is never written: nothing lies in front of the first tile
-                const bool wanted = lane < g.n_slots && !(g.sup == 0u && lane == 0u);
-                bad_c = wanted && (u32)(poll.c >> kSlotShift) != epoch;
-                bc = __ballot(bad_c);
-                if (bc == 0) {
-                    sum_c = uniform64(wave_sum(wanted ? poll.c & kSlotMask : 0ull));
-                    need_c = false;
-                }
-            }
-            if (!(need_a || need_b || need_c)) break;
-            if (++spins > kMaxSpins) {
-                if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
-                break;
-            }
-            const u32 n_bad = (u32)__builtin_popcountll(ba) + (u32)__builtin_popcountll(bb) + (u32)__builtin_popcountll(bc);
-            if (n_bad <= kDirectLanes) {
-                // a few stragglers among the nearest predecessors (the usual case): read just those lanes' entries again
-                __builtin_amdgcn_s_sleep(4);
-                if (need_a && bad_a != 0u) scan_issue(a, g, lane, true, false, false, poll);
-                if (need_b && bad_b != 0u) scan_issue(a, g, lane, false, true, false, poll);
-                if (need_c && bad_c) scan_issue(a, g, lane, false, false, true, poll);
 #ifdef WAH_DIAG
-                ++dg_polls;
+        const u64 base = tile_scan_resolve(a, g, block, le, tile, total, lane, poll, dg_t, &dg_polls);
+#else
+        const u64 base = tile_scan_resolve(a, g, block, le, tile, total, lane, poll, nullptr, nullptr);
 #endif
-                continue;
-            }
-            // the word to wait for: {epoch, ...} in its top bits, whichever array it belongs to
-            const u32 *target;
-            if (need_a) {
-                const u32 hl = 63u - (u32)__builtin_clzll(ba);
-                const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_a, (int)hl);
-                target = block + (g.row - g.row0) * kRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
-            } else if (need_b) {
-                const u32 hl = 63u - (u32)__builtin_clzll(bb);
-                const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_b, (int)hl);
-                target = block + (g.row - 1u - g.row0) * kRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
-            } else {
-                const u32 hl = 63u - (u32)__builtin_clzll(bc);
-                target = block + kScanSlotsAt + 2u * hl + 1u; // high half of the slot
-            }
-            bool timed_out = false;
-            for (;;) {
-                __builtin_amdgcn_s_sleep(8);
-                if ((__hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> kCountBits) == epoch) break;
-                if (++spins > kMaxSpins) {
-                    timed_out = true;
-                    break;
-                }
-            }
-            if (timed_out) {
-                if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
-                break;
-            }
-            scan_issue(a, g, lane, need_a, need_b, need_c, poll);
-#ifdef WAH_DIAG
-            ++dg_polls;
-#endif
-        }
-        DG(4);
-        const u64 base = sum_c + sum_b + sum_a;
-        const u64 end = base + total;
-        if (lane == 0) {
-            s_base = base;
-            if (g.idx == kRowTiles - 1u && g.row - g.row0 == kSuperRows - 1u) // last tile of a superrow
-                __hip_atomic_store(reinterpret_cast<u64 *>(a.gen_desc + (u64)(g.sup + 1u) * kScanBlockWords + kScanSlotsAt),
-                                   ((u64)epoch << kSlotShift) | end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tile == a.n_tiles - 1) {
-                *a.out_words = end;
-                if (a.seg_offsets) a.seg_offsets[a.n_segments] = end;
-                if (end > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
-                if (a.host_result) {
-                    // every scan of the launch can complete now (this one needed all of them), so the error word is final
-                    a.host_result[1] = end;
-                    a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
-                }
-                launch_epoch_end(a.ctrl, le); // every other tile has published, so it has read the epoch: advance it
-            }
-        }
+        if (lane == 0) s_base = base;
     }
     __syncthreads();
 #ifdef WAH_DIAG
@@ -750,6 +767,8 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
         }
     }
 }
+
+#include "wah_compress_pair.inc"
 
 // ===========================================================================
 // Unsegmented ("classic") WAH straight out of the encoder (wah_compress_device_ex, WAH_UNSEGMENTED):
@@ -1223,7 +1242,52 @@ hipError_t launch_compress_nowait(const CompressArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// workgroups that take tile after tile: as many as the chip holds at once (two per CU: registers and LDS), never more
+// than there are tiles.  More would be harmless (a workgroup that finds no tile left exits), fewer resident ones too.
+static uint32_t resident_workgroups() {
+    static const uint32_t n = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        const char *e = std::getenv("WAH_GRID_PER_CU"); // experiments only
+        const int per_cu = e ? std::atoi(e) : 2;
+        return (uint32_t)(cus * (per_cu > 0 ? per_cu : 2));
+    }();
+    return n;
+}
+
+template <bool kAligned>
+static void launch_pairs(const CompressArgs &a, hipStream_t s) {
+    static const bool persist = [] { // experiments only: workgroups that take tile after tile (measured: slower)
+        const char *e = std::getenv("WAH_PERSIST");
+        return e && e[0] == '1';
+    }();
+    const dim3 block(kTileWaves * 64);
+    if (persist) {
+        const dim3 grid(a.n_tiles < resident_workgroups() ? a.n_tiles : resident_workgroups());
+        if (a.wave_segs == 2)
+            hipLaunchKernelGGL((compress_pair_kernel<kAligned, 1, true>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((compress_pair_kernel<kAligned, 2, true>), grid, block, 0, s, a);
+        return;
+    }
+    const dim3 grid(a.n_tiles);
+    if (a.wave_segs == 2)
+        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 1, false>), grid, block, 0, s, a);
+    else if (a.wave_segs == 4)
+        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 2, false>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 3, false>), grid, block, 0, s, a);
+}
+
 hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {
+    if (a.pair_layout) {
+        if (a.fast_segments)
+            launch_pairs<true>(a, s);
+        else
+            launch_pairs<false>(a, s);
+        return hipGetLastError();
+    }
     if (a.unseg_desc) {
         if (a.fast_segments)
             launch_unseg<true>(a, s);
@@ -1257,6 +1321,19 @@ uint32_t compress_wave_segs(uint64_t n_segments) {
     if (n_segments <= 2400) return 1;
     if (n_segments <= 6000) return 2;
     return (uint32_t)kCompressMaxWaveSegs;
+}
+
+// pair-layout kernel (compress_pair_kernel): pairs of segments per wavefront
+uint32_t compress_wave_pairs(uint64_t n_segments) {
+    static const int forced = [] { // experiments only: 0 switches the kernel off
+        const char *e = std::getenv("WAH_WAVE_PAIRS");
+        return e ? std::atoi(e) : -1;
+    }();
+    if (forced >= 0 && forced <= 3) return (uint32_t)forced;
+    // measured on 1 MiB .. 1 GiB bitmaps (tools/scratch/pair_sizes.py)
+    if (n_segments <= 2400) return 1;
+    if (n_segments <= 6000) return 2;
+    return 3;
 }
 
 // wah_bitop_device: both operands must have expanded to the bitmap length the caller named, without errors of their own

@@ -46,6 +46,7 @@ constexpr uint32_t kEpochWrap = (1u << 16) - 1u;  // stored epoch >= this: the n
 constexpr int kCompressTileWaves = WAH_TILE_WAVES;
 constexpr int kCompressMaxWaveSegs = 5; // segments a wavefront compresses one after the other: 1, 2 or this (by bitmap size)
 uint32_t compress_wave_segs(uint64_t n_segments);
+uint32_t compress_wave_pairs(uint64_t n_segments); // pair-layout kernel: pairs of segments per wavefront (0: kernel switched off)
 // scan area of the compress kernel (see compress_tile_kernel): one block per superrow of 64 rows x 256 tiles
 constexpr uint32_t kRowSlots = 65;                 // u64 slots of a superrow: words in front of it, words of each of its rows
 constexpr uint32_t kScanSlotsAt = 64 * 256;        // 32-bit words: the slots follow the superrow's granules
@@ -73,6 +74,7 @@ struct CompressArgs {
     uint64_t n_words;
     uint32_t n_segments;          // ceil(G / 1024)
     uint32_t wave_segs;           // segments per wavefront of this launch (compress_wave_segs)
+    uint32_t pair_layout;         // 1: compress_pair_kernel (a lane owns 32 consecutive groups; wave_segs / 2 pairs per wavefront)
     uint32_t n_tiles;             // ceil(n_segments / (kCompressTileWaves * wave_segs))
     uint32_t fast_segments;       // 1: input 16-byte aligned -> prefetched buffer loads; 0: scalar staging
     uint32_t last_segment_groups; // groups of the last segment (1..1024)

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Time line of compress_pair_kernel (DIAGNOSTIC build, WAH_TUNE=78): per tile, when it started, had its first pair's
+words in registers, finished pass 1, published, finished pass 2, knew its offset (s_memrealtime, 100 MHz); tiles in
+flight over time.  usage: python tools/pair_timeline.py [sparse|clustered|dense ...]"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["WAH_LIB_PATH"] = os.path.join(ROOT, "gpu-wah_amd", "libwah_hip_diag.so")
+os.environ["WAH_TUNE"] = "78"
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+wah = importlib.import_module("gpu-wah_amd")
+n = 268435200
+tile_segs = 16 * int(os.environ.get("WAH_WAVE_PAIRS", "3"))
+for kind in sys.argv[1:] or ["sparse"]:
+    d = {"sparse": lambda: wah.gen_uniform_device(n, 1337, 0.01), "dense": lambda: wah.gen_uniform_device(n, 1337, 0.5),
+         "clustered": lambda: wah.gen_clustered_device(n, 1337)}[kind]()
+    comp = wah.DeviceCompressor(n, indexed=True)
+    comp.run(d)
+    comp.status()
+    comp.run(d)
+    comp.status()
+    n_tiles = (270600 + tile_segs - 1) // tile_segs
+    t = comp.seg_offsets[: n_tiles * 8].cpu().numpy().reshape(n_tiles, 8).astype(np.int64)
+    start, pub, loaded, done, p1, p2, bar2 = (t[:, i] for i in range(7))
+    t0 = start.min()
+    us = lambda x: x / 100.0
+    q = lambda x: f"{us(x.mean()):.2f} (p10 {us(np.percentile(x, 10)):.2f}, p90 {us(np.percentile(x, 90)):.2f})"
+    print(f"--- {kind}: {n_tiles} tiles of {tile_segs} segments, span {us(bar2.max() - t0):.1f} us")
+    print(f"   start -> first pair in registers   {q(loaded - start)}")
+    print(f"   -> wave 0's pass 1 done            {q(p1 - loaded)}")
+    print(f"   -> barrier 1 passed (publish)      {q(pub - p1)}")
+    print(f"   -> pass 2 + parking done           {q(p2 - pub)}")
+    print(f"   -> offset known                    {q(done - p2)}")
+    print(f"   -> barrier 2 passed                {q(bar2 - done)}")
+    print(f"   tile life (without emission)       {q(bar2 - start)}")
+    s = us(start - t0)
+    e = us(bar2 - t0)
+    for x in np.arange(0, e.max() + 10, 10.0):
+        print(f"   {x:6.1f} us: in flight {int(np.sum((s <= x) & (x < e))):4d}  started {int(np.sum(s <= x)):5d}")
+    es = np.sort(e)
+    ss = np.sort(s)[512:]
+    k = min(len(es), len(ss))
+    print(f"   mean (start of the (512 + i)-th tile) - (i-th end): {float(np.mean(ss[:k] - es[:k])):.2f} us")
+    del comp, d

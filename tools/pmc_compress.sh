@@ -21,7 +21,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(R+"/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k=row.get("Kernel_Name","")
-        short = "compress" if "compress_tile_kernel" in k else ("scan" if "decode_scan" in k else ("expand" if "decode_expand" in k else None))
+        short = "compress" if ("compress_tile_kernel" in k or "compress_pair_kernel" in k) else ("sums" if "decode_sums" in k else ("expand" if "decode_expand" in k else None))
         if short: agg[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 with open(R+"/summary.txt","w") as o:
     for k in agg:
