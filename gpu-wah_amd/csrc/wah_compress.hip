@@ -363,7 +363,7 @@ __device__ __forceinline__ void emit_regs(const CompressArgs &a, u64 base, u32 c
 // Wave 0 of a tile, once the tile's count is out and its sweep issued (scan_issue): the tile's output offset, and what
 // the last tile of a row / of a superrow / of the launch leaves behind ("Row scan" above).  Returns the offset.
 __device__ __forceinline__ u64 tile_scan_resolve(const CompressArgs &a, const ScanGeom &g, u32 *const block, const LaunchEpoch &le, u32 tile,
-                                                 u32 total, u32 lane, TileScan &poll, u64 *dg_t, u32 *dg_polls, bool keep_ticket = false) {
+                                                 u32 total, u32 lane, TileScan &poll, u64 *dg_t, u32 *dg_polls) {
     const u32 epoch = le.epoch;
     (void)dg_t;
     (void)dg_polls;
@@ -482,7 +482,7 @@ __device__ __forceinline__ u64 tile_scan_resolve(const CompressArgs &a, const Sc
                 a.host_result[1] = end;
                 a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
             }
-            launch_epoch_end(a.ctrl, le, keep_ticket); // every other tile has published, so it has read the epoch: advance it
+            launch_epoch_end(a.ctrl, le); // every other tile has published, so it has read the epoch: advance it
         }
     }
     return base;
@@ -1242,42 +1242,14 @@ hipError_t launch_compress_nowait(const CompressArgs &a, hipStream_t s) {
     return hipGetLastError();
 }
 
-// workgroups that take tile after tile: as many as the chip holds at once (two per CU: registers and LDS), never more
-// than there are tiles.  More would be harmless (a workgroup that finds no tile left exits), fewer resident ones too.
-static uint32_t resident_workgroups() {
-    static const uint32_t n = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        const char *e = std::getenv("WAH_GRID_PER_CU"); // experiments only
-        const int per_cu = e ? std::atoi(e) : 2;
-        return (uint32_t)(cus * (per_cu > 0 ? per_cu : 2));
-    }();
-    return n;
-}
-
 template <bool kAligned>
 static void launch_pairs(const CompressArgs &a, hipStream_t s) {
-    static const bool persist = [] { // experiments only: workgroups that take tile after tile (measured: slower)
-        const char *e = std::getenv("WAH_PERSIST");
-        return e && e[0] == '1';
-    }();
-    const dim3 block(kTileWaves * 64);
-    if (persist) {
-        const dim3 grid(a.n_tiles < resident_workgroups() ? a.n_tiles : resident_workgroups());
-        if (a.wave_segs == 2)
-            hipLaunchKernelGGL((compress_pair_kernel<kAligned, 1, true>), grid, block, 0, s, a);
-        else
-            hipLaunchKernelGGL((compress_pair_kernel<kAligned, 2, true>), grid, block, 0, s, a);
-        return;
+    const dim3 grid(a.n_tiles), block(kTileWaves * 64);
+    switch (a.wave_segs) {
+    case 2: hipLaunchKernelGGL((compress_pair_kernel<kAligned, 1>), grid, block, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((compress_pair_kernel<kAligned, 2>), grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL((compress_pair_kernel<kAligned, 3>), grid, block, 0, s, a); break;
     }
-    const dim3 grid(a.n_tiles);
-    if (a.wave_segs == 2)
-        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 1, false>), grid, block, 0, s, a);
-    else if (a.wave_segs == 4)
-        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 2, false>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 3, false>), grid, block, 0, s, a);
 }
 
 hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {

@@ -179,10 +179,9 @@ __device__ __forceinline__ LaunchEpoch launch_epoch_begin(u32 *ctrl, u32 tile, u
 }
 
 // one lane of the last tile, after its scan: every other tile has published its granule, so it has read the epoch
-// (keep_ticket: a kernel whose workgroups take tile after tile resets the ticket itself, once its last workgroup has drawn)
-__device__ __forceinline__ void launch_epoch_end(u32 *ctrl, const LaunchEpoch &le, bool keep_ticket = false) {
+__device__ __forceinline__ void launch_epoch_end(u32 *ctrl, const LaunchEpoch &le) {
     if (le.wrap) __hip_atomic_store(ctrl + kCtlWraps, ctrl[kCtlWraps] + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!keep_ticket) __hip_atomic_store(ctrl + kCtlStart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // every tile number has been drawn
+    __hip_atomic_store(ctrl + kCtlStart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // every tile number has been drawn
     __hip_atomic_store(ctrl + kCtlMagic, kWorkspaceMagic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(ctrl + kCtlEpoch, le.epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
