@@ -685,9 +685,6 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
             if (lane == 0)
                 __hip_atomic_store(block + (g.row - g.row0) * kRowTiles + g.idx, (epoch << kGranuleCountBits) | total, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
-            // One round trip of three loads per lane, issued now that the count is out and collected after pass 2: by
-            // then the tiles dispatched before this one have normally published theirs.
-            scan_issue(a, g, lane, true, g.has_prev, true, poll);
         }
 #ifdef WAH_DIAG
         if (a.tune == 77u) { // time line mode: how long does the sweep itself take?
@@ -715,6 +712,9 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
 
     DG(6);
     if (kMode == kTileScan && wave == 0) {
+        // the sweep of the other tiles' counts: one round trip of three loads per lane, issued only now (see
+        // compress_pair_body: issued right behind the publication it mostly finds the nearest predecessors missing)
+        scan_issue(a, g, lane, true, g.has_prev, true, poll);
 #ifdef WAH_DIAG
         const u64 base = tile_scan_resolve(a, g, block, le, tile, total, lane, poll, dg_t, &dg_polls);
 #else
@@ -961,7 +961,6 @@ __device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
         if (lane == 0)
             __hip_atomic_store(my_row + g.idx, ((u64)epoch << 48) | ((u64)total << 32) | (tile_t ? kUnsegT : 0ull) | tile_l, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
-        unseg_issue(block, g.row - g.row0, g.idx, g.n_slots, lane, true, g.has_prev, true, poll);
     }
 
     // ---- pass 2 of all segments: compaction in LDS, final words into registers -----------------------------------------
@@ -978,7 +977,8 @@ __device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
     }
 
     if (wave == 0) {
-        // ---- the tile's offset and the run that is open where it begins ---------------------------------------------------
+        // ---- the tile's offset and the run that is open where it begins (the sweep goes out only now: compress_pair_body) ---
+        unseg_issue(block, g.row - g.row0, g.idx, g.n_slots, lane, true, g.has_prev, true, poll);
         bool need_a = true, need_b = g.has_prev, need_c = true;
         u64 words_a = 0, words_b = 0, words_c = 0, len_a = 0, len_b = 0, len_c = 0;
         bool all_a = true, all_b = true;
@@ -1142,12 +1142,11 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
     compress_tile_body<BitmapSource<kPair, kAligned>, kWaveSegs>(a, src);
 }
 
-// ---- the no-wait route (kTileCount / kTilePlace above): two segments per wave, whatever the size of the bitmap ------
-constexpr u32 kNoWaitWaveSegs = 2;
+// ---- the no-wait route (kTileCount / kTilePlace of compress_pair_body): two pairs per wave, whatever the size of the bitmap ------
+constexpr u32 kNoWaitWaveSegs = 4;
 template <bool kAligned, int kMode>
-__global__ __launch_bounds__(kTileWaves * 64, 6) void compress_nowait_kernel(const CompressArgs a) {
-    BitmapSource<false, kAligned> src;
-    compress_tile_body<BitmapSource<false, kAligned>, kNoWaitWaveSegs, kMode>(a, src);
+__global__ __launch_bounds__(kTileWaves * 64, 4) void compress_nowait_kernel(const CompressArgs a) {
+    compress_pair_body<kAligned, kNoWaitWaveSegs / 2, kMode>(a);
 }
 
 // counts of the tiles -> where every tile's words start (exclusive scan, in place), + everything the last tile of the
