@@ -42,6 +42,7 @@ ABI_SYMBOLS = {
     "wah_compress_device_indexed": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _sz, _vp]),
     "wah_compress_status": (_int, [_vp, _vp]),
     "wah_decompress_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
+    "wah_decompress_device_ex": (_int, [_vp, _u64, _vp, _u64, _vp, ctypes.c_uint, _vp, _sz, _vp]),
     "wah_decompress_scan_device": (_int, [_vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_expand_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_build_index_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
@@ -211,8 +212,8 @@ class DeviceCompressor:
         torch = _torch()
         if indexed and unsegmented:
             raise WahError("an unsegmented stream has no segment index")
-        if no_wait and (indexed or unsegmented):
-            raise WahError("WAH_NO_WAIT applies to the plain compress only")
+        if no_wait and indexed:
+            raise WahError("the flags entry point has no index output (WAH_FORCE_FALLBACK=1 covers the indexed call)")
         self.unsegmented = bool(unsegmented)
         self.no_wait = bool(no_wait)
         self.n_words = int(n_words)
@@ -243,7 +244,8 @@ class DeviceCompressor:
     def _run(self, d_in, n, sp, count_ptr):
         if self.unsegmented or self.no_wait:
             rc = lib().wah_compress_device_ex(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, count_ptr,
-                                              1 if self.unsegmented else 2, self.workspace.data_ptr(), self.ws_bytes, sp)
+                                              (1 if self.unsegmented else 0) | (2 if self.no_wait else 0),
+                                              self.workspace.data_ptr(), self.ws_bytes, sp)
         elif self.seg_offsets is None:
             rc = lib().wah_compress_device(d_in.data_ptr(), n, self.out.data_ptr(), self.capacity, count_ptr,
                                            self.workspace.data_ptr(), self.ws_bytes, sp)
@@ -266,8 +268,10 @@ class DeviceCompressor:
 class DeviceDecompressor:
     """Reusable workspace + output for decoding streams of up to `c_words` words into `out_capacity` words."""
 
-    def __init__(self, c_words, out_capacity_words, device="cuda:0"):
+    def __init__(self, c_words, out_capacity_words, device="cuda:0", no_wait=False):
+        """no_wait: the sums pass by the route in which no workgroup waits for another (include/wah.h: WAH_NO_WAIT)."""
         torch = _torch()
+        self.no_wait = bool(no_wait)
         self.c_words = int(c_words)
         self.capacity = int(out_capacity_words)
         self.ws_bytes = int(lib().wah_decompress_workspace_bytes(self.c_words, self.capacity))
@@ -282,8 +286,9 @@ class DeviceDecompressor:
         c = self.c_words if c_words is None else int(c_words)
         if c > self.c_words or c > d_comp.numel():
             raise WahError("stream larger than this decompressor was sized for")
-        rc = lib().wah_decompress_device(d_comp.data_ptr(), c, self.out.data_ptr(), self.capacity, self.info.data_ptr(),
-                                         self.workspace.data_ptr(), self.ws_bytes, _stream_ptr(torch, stream))
+        rc = lib().wah_decompress_device_ex(d_comp.data_ptr(), c, self.out.data_ptr(), self.capacity, self.info.data_ptr(),
+                                            2 if self.no_wait else 0, self.workspace.data_ptr(), self.ws_bytes,
+                                            _stream_ptr(torch, stream))
         _check(rc, "wah_decompress_device")
 
     def status(self, stream=None):

@@ -36,14 +36,21 @@ inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 inline size_t round256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Workspace layouts.  Everything a launch stamps with its epoch lives in areas whose PLACE depends on the workspace's size
+// only, never on the size of the input: one workspace serves inputs of different sizes in turn (include/wah.h), and an
+// area that moved with the input would let one call's data be read as another call's published entries.  Both layouts
+// are [control block][first half][second half], the halves being (workspace_bytes - control block) / 2 each.
 struct CompressLayout {
     uint64_t n_groups, n_segments, n_tiles;
     uint32_t wave_segs;
-    size_t ctrl_off, desc_off, unseg_off, total;
+    size_t ctrl_off, desc_off, unseg_off, half, total; // total: what an input of this size needs
 };
 
-// [control block][scan area: one block of kScanBlockWords per 64 x 256 tiles, + the block a full last superrow publishes into]
-CompressLayout compress_layout(uint64_t n_words) {
+// first half: scan area of compress_pair_kernel / compress_tile_kernel (one block of kScanBlockWords per 64 x 256 tiles, +
+// the block a full last superrow publishes into); second half: scan area of the unsegmented mode (blocks of
+// kUnsegBlockWords), which the no-wait route borrows for its table of tile counts (offsets below 2^48: never a valid
+// epoch stamp)
+CompressLayout compress_layout(uint64_t n_words, size_t workspace_bytes = 0) {
     CompressLayout l;
     l.n_groups = wah_max_compressed_words(n_words);
     l.n_segments = ceil_div(l.n_groups, wah::kSegGroups);
@@ -51,31 +58,43 @@ CompressLayout compress_layout(uint64_t n_words) {
     l.n_tiles = ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * l.wave_segs);
     // sized for the shortest tiles: a workspace serves any smaller bitmap too
     const uint64_t blocks = ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves) / wah::kScanBlockTiles + 1;
+    static_assert(wah::kUnsegBlockWords >= wah::kScanBlockWords, "the halves are sized by the larger block");
+    const size_t need_half = round256(blocks * wah::kUnsegBlockWords * sizeof(uint32_t));
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
-    l.unseg_off = round256(l.desc_off + blocks * wah::kScanBlockWords * sizeof(uint32_t)); // scan area of the unsegmented mode
-    l.total = round256(l.unseg_off + blocks * wah::kUnsegBlockWords * sizeof(uint32_t));
+    l.total = l.desc_off + 2 * need_half;
+    const size_t w = workspace_bytes ? workspace_bytes : l.total;
+    l.half = w > l.desc_off ? ((w - l.desc_off) / 2) & ~(size_t)255 : 0;
+    l.unseg_off = l.desc_off + l.half;
+    if (l.half < need_half) l.total = w + 1; // (does not fit: the callers compare workspace_bytes with total)
     return l;
 }
 
 struct DecodeLayout {
     uint64_t n_tiles;
-    size_t ctrl_off, desc_off, base_off, flags_off, total, scan_bytes;
+    size_t ctrl_off, desc_off, base_off, flags_off, half, total, scan_bytes;
 };
 
-// [control block][scan area of the sums kernel: one block per 64 x 256 workgroup tiles (+ the one a full last superrow
-//  publishes into)][tile bases][one flag byte per tile]
-DecodeLayout decode_layout(uint64_t c_words) {
+// first half: scan area of the sums kernel (one block per 64 x 256 workgroup tiles, + the one a full last superrow
+// publishes into); second half: tile bases, then one flag byte per tile (rewritten by every call, no epochs)
+DecodeLayout decode_layout(uint64_t c_words, size_t workspace_bytes = 0) {
     DecodeLayout l;
     l.n_tiles = ceil_div(c_words, (uint64_t)wah::kScanTileWords);
     const uint64_t wg_tiles = ceil_div(l.n_tiles, (uint64_t)wah::kSumTilesPerGroup);
     const uint64_t blocks = wg_tiles / wah::kSumScanBlockTiles + 1;
+    const size_t scan_need = blocks * wah::kSumScanBlockWords * sizeof(uint32_t);
+    const size_t base_bytes = round256((l.n_tiles + 4) * sizeof(uint64_t)); // (+ two words for wah_validate_device)
+    const size_t rest_need = base_bytes + round256(l.n_tiles + 16);           // one byte per tile: contains empty fills
+    const size_t need_half = round256(scan_need > rest_need ? scan_need : rest_need);
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
-    l.scan_bytes = blocks * wah::kSumScanBlockWords * sizeof(uint32_t);
-    l.base_off = round256(l.desc_off + l.scan_bytes);
-    l.flags_off = round256(l.base_off + (l.n_tiles + 4) * sizeof(uint64_t)); // (+ two words for wah_validate_device)
-    l.total = round256(l.flags_off + l.n_tiles + 16);                       // one byte per tile: contains empty fills
+    l.total = l.desc_off + 2 * need_half;
+    const size_t w = workspace_bytes ? workspace_bytes : l.total;
+    l.half = w > l.desc_off ? ((w - l.desc_off) / 2) & ~(size_t)255 : 0;
+    l.scan_bytes = l.half; // (the wrap-around clear covers the whole first half, whatever was launched into it)
+    l.base_off = l.desc_off + l.half;
+    l.flags_off = l.base_off + base_bytes;
+    if (l.half < need_half) l.total = w + 1;
     return l;
 }
 
@@ -279,6 +298,13 @@ void *host_result_alloc(size_t bytes, bool *huge) {
     return std::malloc(bytes ? bytes : sizeof(uint32_t));
 }
 
+// WAH_TEST_TIMEOUT=1 (tests only, read per call): the host-pointer entry points treat their first launch as if one of
+// its bounded waits had expired, which sends them down the no-wait route.
+bool test_timeout_hook() {
+    const char *e = std::getenv("WAH_TEST_TIMEOUT");
+    return e && e[0] == '1';
+}
+
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
     set_err(what, e);
@@ -372,13 +398,9 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     g_err[0] = 0;
     // WAH_FORCE_FALLBACK=1: every plain compress launch takes the no-wait route (tests; a GPU shared in ways that starve
     // the scan route's waits).  Read per call: it is a switch for a running process too.
-    if (!no_wait && !d_in2 && !indexed && !unsegmented) {
+    if (!no_wait) {
         const char *f = std::getenv("WAH_FORCE_FALLBACK");
         no_wait = f && f[0] == '1';
-    }
-    if (no_wait && (d_in2 || indexed || unsegmented)) {
-        set_err("WAH_NO_WAIT applies to the plain compress only");
-        return WAH_ERR_ARG;
     }
     if (!d_out_words || !d_workspace || (n_words && ((!d_in && !indexed) || !d_out))) {
         set_err("null pointer");
@@ -388,7 +410,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
         set_err("size out of range or misaligned pointer");
         return WAH_ERR_ARG;
     }
-    const CompressLayout l = compress_layout(n_words);
+    const CompressLayout l = compress_layout(n_words, workspace_bytes);
     if (workspace_bytes < l.total) {
         set_err("workspace too small");
         return WAH_ERR_WORKSPACE;
@@ -397,7 +419,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     char *ws = static_cast<char *>(d_workspace);
     hipError_t e = hipSuccess;
     if (clear_first) {
-        e = wah::launch_clear(ws, l.total, s);
+        e = wah::launch_clear(ws, l.desc_off + 2 * l.half, s);
         if (e != hipSuccess) {
             set_err("clearing the workspace", e);
             return WAH_ERR_HIP;
@@ -434,14 +456,16 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
         if (a.wave_segs > (uint32_t)wah::kCompressUnsegMaxWaveSegs) a.wave_segs = wah::kCompressUnsegMaxWaveSegs;
         a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
     }
-    if (no_wait) { // count / scan / place (compress_nowait_kernel): its own tile shape, the table in the second scan area
-        a.wave_segs = wah::compress_nowait_wave_segs();
-        a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
-        a.tile_counts = reinterpret_cast<uint64_t *>(ws + l.unseg_off);
-    }
     if (indexed) { // groups come from two indexed streams (bitop_tile_kernel): its own tile shape
         a.wave_segs = wah::kIndexedSegsPerWave;
         a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * wah::kIndexedSegsPerWave);
+    }
+    if (no_wait) { // count / scan / place: nobody waits for anybody.  Its own tile shape (two segments per wave; the plain
+                   // compress: two pairs); the table of tile counts lies in the workspace's second half
+        a.wave_segs = (d_in2 || indexed || unsegmented) ? 2u : wah::compress_nowait_wave_segs();
+        a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
+        a.tile_counts = reinterpret_cast<uint64_t *>(ws + l.unseg_off);
+        a.pair_layout = 0;
     }
     a.fast_segments = aligned16(d_in) ? 1u : 0u;
     a.full_segments = (uint32_t)(n_words / wah::kSegWords);
@@ -453,7 +477,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     a.seg_offsets = d_segment_offsets;
     a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
     a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
-    a.scan_words = (l.total - l.desc_off) / sizeof(uint32_t); // both scan areas (the wrap-around clear covers them)
+    a.scan_words = 2 * l.half / sizeof(uint32_t); // both halves (the wrap-around clear covers them, whatever was launched into them)
     a.keep_error = clear_first ? 1 : 0;
     a.host_result = host_result;
 #ifdef WAH_DIAG
@@ -527,8 +551,14 @@ int wah_decompress_status(void *d_workspace, void *stream) { return read_status(
 // front of the launch, which makes it a fresh workspace every time.
 static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                          uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream, bool do_scan,
-                         bool do_expand, bool clear_first = false, uint64_t *host_result = nullptr) {
+                         bool do_expand, bool clear_first = false, uint64_t *host_result = nullptr, bool no_wait = false) {
     g_err[0] = 0;
+    // WAH_FORCE_FALLBACK=1: every sums pass takes the no-wait route (tests; a GPU shared in ways that starve the scan
+    // route's waits).  Read per call: it is a switch for a running process too.
+    if (!no_wait && do_scan) {
+        const char *f = std::getenv("WAH_FORCE_FALLBACK");
+        no_wait = f && f[0] == '1';
+    }
     if (!d_out_info || !d_workspace || (c_words && !d_comp) || (do_expand && out_capacity_words && !d_out)) {
         set_err("null pointer");
         return WAH_ERR_ARG;
@@ -537,7 +567,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         set_err("size out of range or misaligned pointer");
         return WAH_ERR_ARG;
     }
-    const DecodeLayout l = decode_layout(c_words);
+    const DecodeLayout l = decode_layout(c_words, workspace_bytes);
     if (workspace_bytes < l.total) {
         set_err("workspace too small");
         return WAH_ERR_WORKSPACE;
@@ -572,6 +602,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
             a.tile_flags = reinterpret_cast<uint8_t *>(ws + l.flags_off);
             a.aligned16 = aligned16(d_comp) ? 1 : 0;
             a.host_result = host_result;
+            a.no_wait = no_wait ? 1 : 0;
             e = wah::launch_decode_sums(a, s);
             if (e != hipSuccess) {
                 set_err("decode sums kernel launch", e);
@@ -607,6 +638,17 @@ int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_
                          true, true);
 }
 
+int wah_decompress_device_ex(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
+                             uint64_t *d_out_info, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream) {
+    if (flags & ~(unsigned)WAH_NO_WAIT) {
+        g_err[0] = 0;
+        set_err("unknown flag");
+        return WAH_ERR_ARG;
+    }
+    return decode_common(d_comp, c_words, d_out, out_capacity_words, d_out_info, d_workspace, workspace_bytes, stream,
+                         true, true, false, nullptr, (flags & WAH_NO_WAIT) != 0);
+}
+
 int wah_decompress_scan_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_out_info, void *d_workspace,
                                size_t workspace_bytes, void *stream) {
     return decode_common(d_comp, c_words, nullptr, 0, d_out_info, d_workspace, workspace_bytes, stream, true, false);
@@ -629,7 +671,7 @@ int wah_validate_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_re
     // the sums pass gives the tile bases and the totals ([words, groups] land in d_report[0..1] for a moment)
     const int rc = decode_common(d_comp, c_words, nullptr, 0, d_report, d_workspace, workspace_bytes, stream, true, false);
     if (rc != WAH_OK) return rc;
-    const DecodeLayout l = decode_layout(c_words);
+    const DecodeLayout l = decode_layout(c_words, workspace_bytes);
     char *ws = static_cast<char *>(d_workspace);
     // keep the totals aside (behind the tile bases), then build the report
     uint64_t *info = reinterpret_cast<uint64_t *>(ws + l.base_off) + (l.n_tiles + 1);
@@ -663,7 +705,7 @@ int wah_build_index_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d
         }
         return WAH_OK;
     }
-    const DecodeLayout l = decode_layout(c_words);
+    const DecodeLayout l = decode_layout(c_words, workspace_bytes);
     char *ws = static_cast<char *>(d_workspace);
     const hipError_t e = wah::launch_build_index(d_comp, c_words, reinterpret_cast<const uint64_t *>(ws + l.base_off), d_out_info,
                                                  d_segment_offsets, offsets_capacity, reinterpret_cast<uint32_t *>(ws + l.ctrl_off),
@@ -711,7 +753,7 @@ int wah_merge_fills_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d
     // sums pass: tile bases and totals
     const int rc = decode_common(d_comp, c_words, nullptr, 0, info, d_workspace, l.decode_bytes, stream, true, false);
     if (rc != WAH_OK) return rc;
-    const DecodeLayout d = decode_layout(c_words);
+    const DecodeLayout d = decode_layout(c_words, l.decode_bytes);
     wah::MergeArgs a;
     a.comp = d_comp;
     a.c_words = c_words;
@@ -1045,6 +1087,7 @@ uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *ou
     hc.mark();
     uint64_t c = 0;
     if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws, hc.cache.pinned, &c, 1); // status + size: one wait, no copy
+    if (rc == WAH_OK && test_timeout_hook()) rc = WAH_ERR_TIMEOUT;
     if (rc == WAH_ERR_TIMEOUT) {
         // A bounded wait inside the kernel expired: a workgroup this launch depended on did not get to run in time (a GPU
         // shared in a way the arrival tickets do not cover, a preempted queue).  The no-wait route has no such
@@ -1053,9 +1096,11 @@ uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *ou
         host_result[0] = 0;
         rc = compress_device_impl(static_cast<uint32_t *>(d_in), nullptr, 0, nullptr, n_words, static_cast<uint32_t *>(d_out), cap, d_cnt,
                                   nullptr, d_ws, ws_bytes, nullptr, false, host_result, nullptr, false, true);
+        hc.mark(); // the device phase ends with this route's last launch
         if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws, hc.cache.pinned, &c, 1);
-        // (the abandoned launch left its tickets and its epoch half way: the next call starts from a fresh workspace)
-        if (rc == WAH_OK && wah_workspace_init_device(d_ws, ws_bytes, nullptr) != WAH_OK) rc = WAH_ERR_HIP;
+        // (the abandoned launch left its tickets and its epoch half way: the next call starts from a fresh workspace,
+        //  whatever became of this one)
+        if (wah_workspace_init_device(d_ws, ws_bytes, nullptr) != WAH_OK && rc == WAH_OK) rc = WAH_ERR_HIP;
     }
     if (rc != WAH_OK) {
         std::fprintf(stderr, "wah: compress failed: %s\n", g_err);
@@ -1120,7 +1165,7 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     uint64_t info[2] = {0, 0};
     void *d_out = nullptr;
     int rc = WAH_OK;
-    bool expanded = false;
+    bool expanded = false, no_wait = false;
     // An output buffer kept from an earlier call (the reference's callers decompress in loops, source.cpp:70): expand
     // right behind the scan, into what is there -- the expand kernel compares the decoded size with the capacity on the
     // device and writes nothing if it does not fit.  One host round trip for the whole phase instead of two.
@@ -1130,9 +1175,12 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
                            ws0, nullptr, true, true);
         hc.mark();
         if (rc == WAH_OK) rc = read_status_packed(d_ws0, hc.cache.pinned, info, 2); // status + sizes in one copy
+        if (rc == WAH_OK && test_timeout_hook()) rc = WAH_ERR_TIMEOUT;
         if (rc == WAH_OK) {
             d_out = hc.cache.buf[0];
             expanded = true;
+        } else if (rc == WAH_ERR_TIMEOUT) {
+            no_wait = true; // (by the book below, without waits)
         } else if (rc != WAH_ERR_CAPACITY) {
             std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
             return nullptr;
@@ -1142,8 +1190,19 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
         uint64_t *const host_result = reinterpret_cast<uint64_t *>(hc.cache.pinned) + 4; // behind the copy's landing area
         host_result[0] = 0;
         rc = decode_common(static_cast<uint32_t *>(d_comp), c_words, nullptr, 0, d_info, d_ws0, ws0, nullptr, true, false, false,
-                           c_words ? host_result : nullptr);
+                           c_words ? host_result : nullptr, no_wait);
         if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws0, hc.cache.pinned, info, 2); // status + sizes: one wait, no copy
+        if (rc == WAH_OK && !no_wait && test_timeout_hook()) rc = WAH_ERR_TIMEOUT;
+        if (rc == WAH_ERR_TIMEOUT && !no_wait) {
+            // A bounded wait inside the sums kernel expired (see wah_compress): the no-wait route has no such dependency --
+            // per-tile totals, then one scan launch, the reference's own shape (decompress.cu:66-80).
+            std::fprintf(stderr, "wah: decompress: in-kernel wait expired, taking the no-wait route\n");
+            no_wait = true;
+            host_result[0] = 0;
+            rc = decode_common(static_cast<uint32_t *>(d_comp), c_words, nullptr, 0, d_info, d_ws0, ws0, nullptr, true, false, false,
+                               c_words ? host_result : nullptr, true);
+            if (rc == WAH_OK) rc = wait_host_result(host_result, d_ws0, hc.cache.pinned, info, 2);
+        }
         if (rc != WAH_OK) {
             std::fprintf(stderr, "wah: decompress failed: %s\n", g_err);
             return nullptr;
@@ -1161,6 +1220,8 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     }
     const uint64_t n_out = info[0], groups = info[1];
     t_dev = hc.since_mark();
+    // (after a timeout the abandoned launch left its tickets and its epoch half way: the next call starts from a fresh workspace)
+    if (no_wait && wah_workspace_init_device(d_ws0, ws0, nullptr) != WAH_OK) return nullptr;
 
     // phase 3: D2H + free (decompress.cu:124-131).  The reference hands back a buffer of G words
     // (one per group) of which ceil(31 G / 32) are meaningful; we keep the size and zero the rest.

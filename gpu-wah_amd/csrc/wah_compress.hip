@@ -621,9 +621,9 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
     // ---- launch epoch (wah_device.hpp): the same value for every workgroup of the launch --------------------------------
     LaunchEpoch le = {};
     if (kMode == kTileScan) {
-        le = launch_epoch_begin(a.ctrl, tile, a.gen_desc, a.scan_words, a.keep_error);
+        le = launch_epoch_begin(a.ctrl, tile, a.n_tiles, a.gen_desc, a.scan_words, a.keep_error);
         if (le.bad) {
-            if (tile == a.n_tiles - 1 && threadIdx.x == 0) *a.out_words = 0;
+            if (blockIdx.x == 0 && threadIdx.x == 0) *a.out_words = 0;
             return;
         }
     } else if (kMode == kTileCount && tile == 0 && threadIdx.x == 0 && !a.keep_error) {
@@ -847,7 +847,10 @@ __device__ __forceinline__ bool fold_right(const bool (&valid)[4], const bool (&
     return false;
 }
 
-template <bool kAligned, u32 kWaveSegs>
+// kMode: kTileScan = the one launch described above; kTileCount / kTilePlace = the two halves of its NO-WAIT route
+// (tile = blockIdx, nobody waits): count leaves {words, (T, L)} of every tile in a table, unseg_offsets_kernel turns them
+// into {first word, length of the run that is open where the tile begins}, place does the tile again and writes.
+template <bool kAligned, u32 kWaveSegs, int kMode = kTileScan>
 __device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
     __shared__ __attribute__((aligned(16))) u32 s_out[kTileWaves][kOutWords];
     __shared__ __attribute__((aligned(16))) unsigned short s_pos[kTileWaves][kPosEntries];
@@ -860,12 +863,17 @@ __device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
-    const u32 tile = draw_tile(a.ctrl, &s_tile);
+    const u32 tile = kMode == kTileScan ? draw_tile(a.ctrl, &s_tile) : blockIdx.x;
     const u32 seg0 = (tile * kTileWaves + wave) * kWaveSegs;
-    const LaunchEpoch le = launch_epoch_begin(a.ctrl, tile, a.gen_desc, a.scan_words, a.keep_error);
-    if (le.bad) {
-        if (tile == a.n_tiles - 1 && threadIdx.x == 0) *a.out_words = 0;
-        return;
+    LaunchEpoch le = {};
+    if (kMode == kTileScan) {
+        le = launch_epoch_begin(a.ctrl, tile, a.n_tiles, a.gen_desc, a.scan_words, a.keep_error);
+        if (le.bad) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) *a.out_words = 0;
+            return;
+        }
+    } else if (kMode == kTileCount && tile == 0 && threadIdx.x == 0 && !a.keep_error) {
+        __hip_atomic_store(a.ctrl + kCtlError, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const u32 epoch = le.epoch;
 
@@ -958,10 +966,17 @@ __device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
                 tile_l = uniform32(s_l[w]);
             }
         }
-        if (lane == 0)
+        if (kMode == kTileCount) {
+            if (lane == 0) {
+                a.tile_counts[2ull * tile] = total;
+                a.tile_counts[2ull * tile + 1] = (tile_t ? kSlotT : 0ull) | tile_l;
+            }
+        } else if (kMode == kTileScan && lane == 0) {
             __hip_atomic_store(my_row + g.idx, ((u64)epoch << 48) | ((u64)total << 32) | (tile_t ? kUnsegT : 0ull) | tile_l, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    if (kMode == kTileCount) return;
 
     // ---- pass 2 of all segments: compaction in LDS, final words into registers -----------------------------------------
 #pragma unroll
@@ -976,7 +991,15 @@ __device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
         }
     }
 
-    if (wave == 0) {
+    if (kMode == kTilePlace && wave == 0) { // both out of the table (unseg_offsets_kernel)
+        u64 c = a.tile_counts[2ull * tile + 1];
+        for (u32 w = 0; w < kTileWaves; ++w) {
+            if (lane == 0) s_carry[w] = (u32)c;
+            c = uniform32(s_t[w]) ? c + uniform32(s_l[w]) : (u64)uniform32(s_l[w]);
+        }
+        if (lane == 0) s_base = a.tile_counts[2ull * tile];
+    }
+    if (kMode == kTileScan && wave == 0) {
         // ---- the tile's offset and the run that is open where it begins (the sweep goes out only now: compress_pair_body) ---
         unseg_issue(block, g.row - g.row0, g.idx, g.n_slots, lane, true, g.has_prev, true, poll);
         bool need_a = true, need_b = g.has_prev, need_c = true;
@@ -1136,10 +1159,73 @@ __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compr
     compress_unseg_body<kAligned, kWaveSegs>(a);
 }
 
+// ---- the no-wait route of the unsegmented mode: two segments per wave, whatever the size of the bitmap --------------
+template <bool kAligned, int kMode>
+__global__ __launch_bounds__(kTileWaves * 64, 4) void compress_unseg_nowait_kernel(const CompressArgs a) {
+    compress_unseg_body<kAligned, 2, kMode>(a);
+}
+
+// {words, (T, L)} of every tile -> {first word, length of the run that is open where the tile begins}, in place; + what
+// the last tile of the scan route leaves behind.  ONE wavefront: the (T, L) of consecutive tiles fold like
+//   (T1, L1) . (T2, L2) = (T1 & T2, T2 ? L1 + L2 : L2)
+// which is associative, so 64 tiles at a time go through a wave scan and the carry of the batches before them is applied
+// on top (a 1 GiB bitmap has 17 000 tiles of 16 segments).
+__global__ __launch_bounds__(64) void unseg_offsets_kernel(const CompressArgs a) {
+    const u32 lane = lane_id();
+    u64 words_front = 0, run_front = 0; // in front of the batch: words, length of the open run
+    for (u64 t0 = 0; t0 < a.n_tiles; t0 += 64u) {
+        const u64 t = t0 + lane;
+        const bool in = t < a.n_tiles;
+        const u64 cnt = in ? a.tile_counts[2 * t] : 0ull;
+        const u64 tl = in ? a.tile_counts[2 * t + 1] : kSlotT; // (behind the end: transparent, length 0)
+        u64 wsum = cnt, len = tl & kSlotLMask;
+        bool tr = (tl & kSlotT) != 0;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { // inclusive scan of both
+            const u64 w2 = __shfl_up(wsum, off), l2 = __shfl_up(len, off);
+            const bool t2 = __shfl_up((int)tr, off) != 0;
+            if (lane >= (u32)off) {
+                wsum += w2;
+                if (tr) len += l2;
+                tr = tr && t2;
+            }
+        }
+        // exclusive values = the inclusive ones of the lane below, on top of what lies in front of the batch
+        const u64 w_ex = __shfl_up(wsum, 1), l_ex = __shfl_up(len, 1);
+        const bool t_ex = __shfl_up((int)tr, 1) != 0;
+        const u64 my_words = words_front + (lane ? w_ex : 0ull);
+        const u64 my_run = lane ? (t_ex ? run_front + l_ex : l_ex) : run_front;
+        if (in) {
+            a.tile_counts[2 * t] = my_words;
+            a.tile_counts[2 * t + 1] = my_run;
+        }
+        const u64 w_all = __shfl(wsum, 63), l_all = __shfl(len, 63);
+        const bool t_all = __shfl((int)tr, 63) != 0;
+        words_front += w_all;
+        run_front = t_all ? run_front + l_all : l_all;
+    }
+    if (lane == 0) {
+        const u64 end = words_front;
+        *a.out_words = end;
+        if (end > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+        if (a.host_result) {
+            a.host_result[1] = end;
+            a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
+        }
+    }
+}
+
 template <bool kPair, bool kAligned, u32 kWaveSegs>
 __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compress_tile_kernel(const CompressArgs a) {
     BitmapSource<kPair, kAligned> src;
     compress_tile_body<BitmapSource<kPair, kAligned>, kWaveSegs>(a, src);
+}
+
+// ---- the no-wait route of the pair mode (wah_bitop_device's combining compress): two segments per wave ----------------
+template <int kMode>
+__global__ __launch_bounds__(kTileWaves * 64, 4) void compress_tile_pair_nowait_kernel(const CompressArgs a) {
+    BitmapSource<true, true> src;
+    compress_tile_body<BitmapSource<true, true>, 2, kMode>(a, src);
 }
 
 // ---- the no-wait route (kTileCount / kTilePlace of compress_pair_body): two pairs per wave, whatever the size of the bitmap ------
@@ -1187,6 +1273,7 @@ __global__ __launch_bounds__(1024) void tile_offsets_kernel(const CompressArgs a
 // from the segment decoder instead of the bitmap.  Nothing of bitmap size is written or read: traffic = 4 C_A + 4 C_B
 // + 4 C_out (+ the indexes).  A range that is not exactly its segment (not a stream of compress() for this bitmap) is
 // reported as WAH_ERR_STREAM; the output is then undefined but every access stays inside the buffers.
+template <int kMode>
 __global__ __launch_bounds__(kTileWaves * 64, 4) void bitop_tile_kernel(const CompressArgs a, const BitopOperands ops) {
     IndexedSource src;
     src.sa = SegmentsArgs{};
@@ -1199,8 +1286,8 @@ __global__ __launch_bounds__(kTileWaves * 64, 4) void bitop_tile_kernel(const Co
     src.offs_a = ops.offs_a;
     src.offs_b = ops.offs_b;
     src.op = ops.op;
-    compress_tile_body<IndexedSource, kIndexedSegsPerWave>(a, src);
-    if (__any(src.bad) && lane_id() == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+    compress_tile_body<IndexedSource, kIndexedSegsPerWave, kMode>(a, src);
+    if (kMode != kTileCount && __any(src.bad) && lane_id() == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
 }
 
 } // namespace
@@ -1229,6 +1316,24 @@ uint32_t compress_nowait_wave_segs() { return kNoWaitWaveSegs; }
 
 hipError_t launch_compress_nowait(const CompressArgs &a, hipStream_t s) {
     const dim3 grid(a.n_tiles), block(kTileWaves * 64);
+    if (a.in2) { // pair mode
+        hipLaunchKernelGGL(compress_tile_pair_nowait_kernel<kTileCount>, grid, block, 0, s, a);
+        hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(compress_tile_pair_nowait_kernel<kTilePlace>, grid, block, 0, s, a);
+        return hipGetLastError();
+    }
+    if (a.unseg_desc) { // unsegmented mode
+        if (a.fast_segments) {
+            hipLaunchKernelGGL((compress_unseg_nowait_kernel<true, kTileCount>), grid, block, 0, s, a);
+            hipLaunchKernelGGL(unseg_offsets_kernel, dim3(1), dim3(64), 0, s, a);
+            hipLaunchKernelGGL((compress_unseg_nowait_kernel<true, kTilePlace>), grid, block, 0, s, a);
+        } else {
+            hipLaunchKernelGGL((compress_unseg_nowait_kernel<false, kTileCount>), grid, block, 0, s, a);
+            hipLaunchKernelGGL(unseg_offsets_kernel, dim3(1), dim3(64), 0, s, a);
+            hipLaunchKernelGGL((compress_unseg_nowait_kernel<false, kTilePlace>), grid, block, 0, s, a);
+        }
+        return hipGetLastError();
+    }
     if (a.fast_segments) {
         hipLaunchKernelGGL((compress_nowait_kernel<true, kTileCount>), grid, block, 0, s, a);
         hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, a);
@@ -1276,7 +1381,14 @@ hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_bitop_tiles(const CompressArgs &a, const BitopOperands &ops, hipStream_t s) {
-    hipLaunchKernelGGL(bitop_tile_kernel, dim3(a.n_tiles), dim3(kTileWaves * 64), 0, s, a, ops);
+    const dim3 grid(a.n_tiles), block(kTileWaves * 64);
+    if (a.tile_counts) { // the no-wait route: count, scan, place (nobody waits for anybody; the operands are decoded twice)
+        hipLaunchKernelGGL(bitop_tile_kernel<kTileCount>, grid, block, 0, s, a, ops);
+        hipLaunchKernelGGL(tile_offsets_kernel, dim3(1), dim3(1024), 0, s, a);
+        hipLaunchKernelGGL(bitop_tile_kernel<kTilePlace>, grid, block, 0, s, a, ops);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(bitop_tile_kernel<kTileScan>, grid, block, 0, s, a, ops);
     return hipGetLastError();
 }
 

@@ -74,22 +74,31 @@ __device__ __forceinline__ void sum_scan_issue(u32 *block, u32 row_in_super, u32
 
 // kWaveTiles: expand tiles a wavefront sums one after the other (long streams: 4, so that ticket, barrier and scan are
 // paid once per 128 KiB... 512 KiB of stream; short streams: 1, more workgroups)
-template <u32 kWaveTiles>
+// kNoWait: the first launch of the NO-WAIT route (WAH_NO_WAIT / WAH_FORCE_FALLBACK=1, and what decompress() takes by
+// itself after a WAH_ERR_TIMEOUT): workgroup tile = blockIdx, no ticket, no epoch; every expand tile's total goes to
+// tile_base[] as it is, and sums_offsets_kernel makes bases of them in a second launch -- getCounts ->
+// thrust::exclusive_scan (decompress.cu:66-80) over one entry per 4096 words instead of one per word.
+template <u32 kWaveTiles, bool kNoWait = false>
 __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanArgs a) {
     __shared__ u64 s_part[kSumWaves * kWaveTiles];
     __shared__ u32 s_tile;
 
     const u32 lane = lane_id();
     const u32 wave = wave_id();
-    const u32 wt = draw_tile(a.ctrl, &s_tile);     // workgroup tile: arrival order (wah_device.hpp)
+    const u32 wt = kNoWait ? blockIdx.x : draw_tile(a.ctrl, &s_tile); // workgroup tile: arrival order (wah_device.hpp)
     const u32 n_tiles = (u32)a.n_tiles;            // expand tiles (4096 words)
     const u32 n_wg_tiles = gridDim.x;
     const u32 et0 = (wt * kSumWaves + wave) * kWaveTiles; // this wave's expand tiles: et0 .. et0 + kWaveTiles - 1
 
-    const LaunchEpoch le = launch_epoch_begin(a.ctrl, wt, a.gen_desc, a.scan_words, 0);
-    if (le.bad) {
-        if (wt == n_wg_tiles - 1 && threadIdx.x == 0) a.info[0] = a.info[1] = 0;
-        return;
+    LaunchEpoch le = {};
+    if (!kNoWait) {
+        le = launch_epoch_begin(a.ctrl, wt, n_wg_tiles, a.gen_desc, a.scan_words, 0);
+        if (le.bad) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) a.info[0] = a.info[1] = 0;
+            return;
+        }
+    } else if (wt == 0 && threadIdx.x == 0) { // a new launch: forget the previous one's status (nothing of this launch raises an error)
+        __hip_atomic_store(a.ctrl + kCtlError, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const u32 epoch = le.epoch;
 
@@ -163,6 +172,10 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
     // ---- wave 0: the workgroup tile's total goes out, then the groups in front of it ---------------------------------
     static_assert(kSumWaves * kWaveTiles <= 64, "one lane per expand tile of the workgroup tile");
     const u64 part = lane < kSumWaves * kWaveTiles ? s_part[lane] : 0ull;
+    if (kNoWait) { // totals only (wave 0: et0 = the workgroup tile's first expand tile); sums_offsets_kernel does the rest
+        if (lane < kSumWaves * kWaveTiles && et0 + lane < n_tiles) a.tile_base[et0 + lane] = part < kSumSaturate ? part : kSumSaturate;
+        return;
+    }
     const u64 incl_part = wave_scan_incl(part, lane);
     u64 total = uniform64(__shfl(incl_part, 63));
     bool overflow = total >= kSumSaturate;
@@ -816,7 +829,49 @@ __global__ __launch_bounds__(kSegDecodeWaves * 64, 6) void bitop_many_segments_k
 
 } // namespace
 
+// second launch of the no-wait route: totals of the expand tiles -> groups in front of every tile (exclusive scan in
+// place, saturating), + everything the last workgroup tile of the scan route leaves behind.  One workgroup: the table
+// has one entry per 16 KiB of stream (a 1 GiB stream: 65 536 of them).
+__global__ __launch_bounds__(1024) void sums_offsets_kernel(const ScanArgs a) {
+    __shared__ u64 s_wave[16];
+    __shared__ u64 s_carry;
+    const u32 lane = lane_id(), wave = wave_id();
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 t0 = 0; t0 < a.n_tiles; t0 += 1024u) {
+        const u64 t = t0 + threadIdx.x;
+        const u64 mine = t < a.n_tiles ? a.tile_base[t] : 0ull; // (each < 2^47 + 1: sixteen of them cannot wrap 64 bits)
+        const u64 incl = wave_scan_incl(mine, lane);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        u64 front = s_carry;
+        for (u32 w = 0; w < wave; ++w) front = sat_add(front, s_wave[w]);
+        if (t < a.n_tiles) a.tile_base[t] = sat_add(front, incl - mine);
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = sat_add(front, incl);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const u64 end = s_carry;
+        if (end >= kSumSaturate) atomicOr(a.ctrl + kCtlError, kErrStream);
+        a.tile_base[a.n_tiles] = end;
+        a.info[1] = end;
+        a.info[0] = (31ull * end + 31ull) / 32ull; // decompress.cu:84-93
+        if (a.host_result) {
+            a.host_result[1] = (31ull * end + 31ull) / 32ull;
+            a.host_result[2] = end;
+            a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
+        }
+    }
+}
+
 hipError_t launch_decode_sums(const ScanArgs &a, hipStream_t s) {
+    if (a.no_wait) {
+        const u64 wg_tiles = (a.n_tiles + kSumWaves - 1) / kSumWaves;
+        hipLaunchKernelGGL((decode_sums_kernel<1, true>), dim3((unsigned)wg_tiles), dim3(kSumWaves * 64), 0, s, a);
+        hipLaunchKernelGGL(sums_offsets_kernel, dim3(1), dim3(1024), 0, s, a);
+        return hipGetLastError();
+    }
     // long streams: four expand tiles per wave (ticket, barrier and scan once per 512 KiB); short ones: more workgroups
 #ifndef WAH_SUM_TILES
 #define WAH_SUM_TILES 4

@@ -136,11 +136,14 @@ __device__ __forceinline__ u32 draw_tile(u32 *ctrl, u32 *s_tile) {
     return uniform32(*s_tile);
 }
 
-__device__ __forceinline__ LaunchEpoch launch_epoch_begin(u32 *ctrl, u32 tile, u32 *scan_area, u64 scan_words, int keep_error) {
+__device__ __forceinline__ LaunchEpoch launch_epoch_begin(u32 *ctrl, u32 tile, u32 n_tiles, u32 *scan_area, u64 scan_words, int keep_error) {
     LaunchEpoch le;
     const u32 stored = uniform32(ctrl[kCtlEpoch]);
     const u32 magic = uniform32(ctrl[kCtlMagic]);
-    le.bad = magic != 0u && magic != kWorkspaceMagic; // neither a zeroed nor a used workspace
+    // neither a zeroed nor a used workspace: a foreign magic word, an epoch no launch can have left, or a ticket counter
+    // that did not start at zero -- a tile number outside the grid, checked BEFORE anything is indexed with it (recycled
+    // memory often reads as magic == 0 with garbage elsewhere)
+    le.bad = (magic != 0u && magic != kWorkspaceMagic) || stored > kEpochWrap || tile >= n_tiles;
     le.wrap = stored >= kEpochWrap;
     le.epoch = (stored == 0u || le.wrap) ? 1u : stored;
     if (le.bad) {

@@ -107,6 +107,7 @@ struct ScanArgs {
     uint8_t *tile_flags; // n_tiles: 1 = the tile contains a fill word of count 0
     int aligned16;
     uint64_t *host_result; // optional, page-locked HOST memory: [0] = 1 | error bits << 32, [1..2] = info, by the last tile
+    int no_wait;           // 1: the no-wait route (per-tile totals, then one scan launch): nobody waits for anybody
 };
 
 struct ExpandArgs {

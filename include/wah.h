@@ -147,6 +147,16 @@ int wah_compress_status(void *d_workspace, void *stream);
 int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                           uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* The same with flags.  WAH_NO_WAIT: the sums pass by a route in which no workgroup waits for another -- every 4096-word
+ * tile's group total to a table, then one scan launch over the table (the reference's getCounts ->
+ * thrust::exclusive_scan, decompress.cu:66-80, with one entry per tile instead of one per word); the expand pass never
+ * waits anyway.  It is what decompress() takes by itself when a bounded wait of the one-launch sums kernel has expired
+ * (WAH_ERR_TIMEOUT), and what WAH_FORCE_FALLBACK=1 in the environment selects for every call.  The route reads nothing
+ * of the workspace's earlier content; before the scan route is used again after a WAH_ERR_TIMEOUT the workspace must be
+ * initialised again (wah_workspace_init_device). */
+int wah_decompress_device_ex(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
+                             uint64_t *d_out_info, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* Decoding through the segment index of wah_compress_device_indexed(): segments [first_segment, first_segment +
  * n_segments) of the bitmap (992 words each, the bitmap's last one shorter) are written to d_out[0 ..).  A stream of
  * compress() never lets a fill cross a segment (compress.cu:129-146: one block per 992 words, fills merged inside

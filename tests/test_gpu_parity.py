@@ -480,8 +480,11 @@ def test_no_wait_route(wah, oracle, monkeypatch):
         assert rc == 0
         got = _host(normal.result())
         assert np.array_equal(got, want if flags != 1 else _py_merge_fills(want)), flags
-    # not combinable with the unsegmented mode
+    # the unsegmented mode has its no-wait route too (count incl. (T, L) -> scan -> place), an unknown flag is refused
     assert lib.wah_compress_device_ex(d.data_ptr(), len(data), normal.out.data_ptr(), normal.capacity, normal.count.data_ptr(), 3,
+                                      normal.workspace.data_ptr(), normal.ws_bytes, None) == 0
+    assert np.array_equal(_host(normal.result()), _py_merge_fills(want))
+    assert lib.wah_compress_device_ex(d.data_ptr(), len(data), normal.out.data_ptr(), normal.capacity, normal.count.data_ptr(), 4,
                                       normal.workspace.data_ptr(), normal.ws_bytes, None) == -1
     # an output capacity below C is reported, nothing is written past it
     guard = torch.full((len(data),), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
@@ -500,6 +503,39 @@ def test_no_wait_route(wah, oracle, monkeypatch):
     monkeypatch.delenv("WAH_FORCE_FALLBACK")
     normal.run(d)
     assert np.array_equal(_host(normal.result()), want)
+    # the decoder's sums pass: per-tile totals + one scan launch instead of the one-launch row scan; one workspace, both routes
+    stream = _dev(want)
+    ref = oracle.decompress(want)
+    dec = wah.DeviceDecompressor(len(want), len(data) + 1)
+    for flags in (2, 0, 2, 0):
+        rc = lib.wah_decompress_device_ex(stream.data_ptr(), len(want), dec.out.data_ptr(), dec.capacity, dec.info.data_ptr(), flags,
+                                          dec.workspace.data_ptr(), dec.ws_bytes, None)
+        assert rc == 0
+        assert np.array_equal(_host(dec.result()), ref), flags
+    assert lib.wah_decompress_device_ex(stream.data_ptr(), len(want), dec.out.data_ptr(), dec.capacity, dec.info.data_ptr(), 1,
+                                        dec.workspace.data_ptr(), dec.ws_bytes, None) == -1
+    # a stream whose totals saturate is still reported
+    huge = _dev(np.full(5000, 0xBFFFFFFF, dtype=np.uint32))
+    big = wah.DeviceDecompressor(5000, 1024, no_wait=True)
+    big.run(huge)
+    with pytest.raises(wah.WahError, match="capacity|stream"):
+        big.status()
+
+
+def test_timeout_takes_the_no_wait_route(wah, oracle, monkeypatch):
+    """compress() / decompress() after a WAH_ERR_TIMEOUT of their one-launch kernels (forced by the test hook: the first launch
+    is treated as if a bounded wait had expired): the no-wait route delivers the same result, the device-phase timing covers
+    it, and the kept workspace is usable by the next ordinary call."""
+    data = oracle.gen_uniform(992 * 300 + 7, 21, 0.02)
+    want = oracle.compress(data)
+    monkeypatch.setenv("WAH_TEST_TIMEOUT", "1")
+    got, t = wah.compress(data, with_timings=True)
+    assert np.array_equal(got, want) and t.device_ms > 0
+    back, t = wah.decompress(got, with_timings=True)
+    assert np.array_equal(back[: len(data)], data) and t.device_ms > 0
+    monkeypatch.delenv("WAH_TEST_TIMEOUT")
+    assert np.array_equal(wah.compress(data), want)
+    assert np.array_equal(wah.decompress(want)[: len(data)], data)
 
 
 # ---------------------------------------------------------------- bitwise operations on compressed bitmaps
@@ -617,6 +653,12 @@ def test_workspace_serves_different_sizes_in_turn(wah, oracle):
         assert np.array_equal(_host(dec.result())[:n], data), n
 
 
+_SCAN_ROUTE_ONLY = pytest.mark.skipif(os.environ.get("WAH_FORCE_FALLBACK") == "1",
+                                      reason="tests the scan route's workspace protocol (epochs, tickets); WAH_FORCE_FALLBACK=1 "
+                                             "sends every launch down the no-wait route, which reads nothing of the workspace")
+
+
+@_SCAN_ROUTE_ONLY
 def test_launch_epoch_wraps_around(wah, oracle):
     """The epoch that stamps a launch's granules has 16 bits.  Start a workspace just below the end of the range: the
     launches that cross it (the wrapping one has tile 0 clear the scan area while the others wait) give the same
@@ -643,6 +685,7 @@ def test_launch_epoch_wraps_around(wah, oracle):
     assert int(comp.workspace[:1024].view(torch.int32)[66].item()) == 1          # kCtlWraps
 
 
+@_SCAN_ROUTE_ONLY
 def test_uninitialised_workspace_is_reported(wah, oracle):
     """A workspace that is neither zeroed nor left by an earlier launch: WAH_ERR_WORKSPACE, not a wrong stream."""
     import torch
@@ -664,6 +707,25 @@ def test_uninitialised_workspace_is_reported(wah, oracle):
     with pytest.raises(wah.WahError, match="not initialised"):
         dec.status()
     torch.cuda.synchronize()
+    # what recycled memory usually looks like: magic word 0 ("fresh") with garbage elsewhere.  A ticket counter that does
+    # not start at zero hands out tile numbers outside the grid, an epoch no launch can have left is garbage: both are
+    # reported before anything is indexed with them (kCtlStart = word 0, kCtlEpoch = word 64 of the control block).
+    for word, value in ((0, 0x7FFF0000), (64, 0x12345678)):
+        comp2 = wah.DeviceCompressor(n)
+        comp2.workspace.view(torch.int32)[word] = value
+        comp2.run(_dev(data))
+        with pytest.raises(wah.WahError, match="not initialised"):
+            comp2.status()
+        dec2 = wah.DeviceDecompressor(comp.count.item(), n + 1)
+        dec2.workspace.view(torch.int32)[word] = value
+        dec2.run(comp.out)
+        with pytest.raises(wah.WahError, match="not initialised"):
+            dec2.status()
+        un = wah.DeviceCompressor(n, unsegmented=True)
+        un.workspace.view(torch.int32)[word] = value
+        un.run(_dev(data))
+        with pytest.raises(wah.WahError, match="not initialised"):
+            un.status()
 
 
 def test_two_host_threads_two_streams_one_device(wah, oracle):
