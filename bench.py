@@ -21,13 +21,15 @@ barrier-bracketed wall clock.  There is no collective on the data path and RCCL 
 scalars of the report (bytes, slowest rank's time) and the barriers go over gloo on 127.0.0.1.
 
 The JSON line also carries
-  roofline     : the dominant kernel (compress_tile_kernel) against the HBM roof.  achieved = algorithmic bytes per
+  roofline     : the dominant kernel (compress_pair_kernel) against the HBM roof.  achieved = algorithmic bytes per
                  launch (4N + 4C) / its average launch duration inside the round trip, measured
                  here with device events on the stream it runs on; launch_ms_isolated = the same kernel in a
                  compress-only loop (in the round trip it starts while the expand kernel's 1 GiB of writes is still
                  draining from the memory-side cache).  `traffic` = HBM bytes per launch from the PMC passes recorded
                  in profiles/traffic.json (rocprofv3 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes + WRITE_SIZE):
                  a number replayed from that profile, not counted in this run ("traffic_measured_in_run": false).
+  columns      : side block (never `value`): BASELINE configs[4] measured by the same command -- this rank's share of
+                 the 1024 independent 128 MiB columns, 5 steps -- with its own roofline block; --no-columns leaves it out.
   cpu_baseline : the CPU oracle (a port of the reference algorithm -- the reference has no CPU path and its CUDA
                  cannot run here) timed on a bounded sample of the same workload on this box's host cores.
 
@@ -81,6 +83,8 @@ def parse(argv=None):
                     help="columns workload: HIP streams the launches are spread over (one compressor = output buffer + workspace each)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="size of the CPU-baseline sample (default: the whole 1 GiB bitmap, about 10 s of host work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-columns", action="store_true", help="round-trip workloads: leave out the `columns` side block (configs[4])")
+    ap.add_argument("--columns-steps", type=int, default=5, help="steps of the `columns` side block")
     ap.add_argument("--seed", type=int, default=1337)
     ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when this process starts the ranks itself")
     ap.add_argument("--dry-launch", action="store_true", help="print the launcher command this call would run and exit")
@@ -207,6 +211,111 @@ def column_plan(n_columns, rank, world, per_launch):
     return mine, batches
 
 
+def columns_measurement(args, dev, rank, world, dist, cpu_only, steps, warmup, desc):
+    """BASELINE configs[4]: compress() of this rank's share of the independent 128 MiB columns (column c on rank c mod N),
+    resident in HBM, `columns_per_launch` columns per launch, the launches round robin over a few streams.  Returns the
+    JSON object of the measurement on rank 0 (None elsewhere).  Every launch is checked once, outside the timed region,
+    one launch at a time (status + a C that fits its buffer); inside the timed region the launches of a stream write
+    their streams into that stream's output buffer one after the other -- nothing consumes them, the figure is the
+    compressor's throughput."""
+    import torch
+
+    n = args.words if (args.words and args.workload == "columns") else COLUMN_WORDS
+    n_columns = args.columns or COLUMNS_TOTAL
+    mine, batches = column_plan(n_columns, rank, world, 1 if args.per_column_launches else args.columns_per_launch)
+    c_words_rank = 0.0
+    one_stream_ms = None
+    n_streams = 1
+    if cpu_only:
+        def step():
+            pass
+    else:
+        wah = importlib.import_module("gpu-wah_amd")
+        wah.lib()
+        specs = [wah.columns.column_spec(c, n, args.seed) for c in mine]
+        batched = n % wah.columns.SEGMENT_WORDS == 0 and not args.per_column_launches
+        # all of the rank's columns stay resident: one [columns, n] matrix, generated once
+        matrix = wah.columns.make_column_matrix(wah, specs, dev) if specs else None
+        widest = max((len(b) for b in batches), default=1)
+        # the launches go round robin over a few streams, each with its own compressor (output buffer + workspace):
+        # the tail of one launch overlaps the start of the next ("just per-GPU streams", north_star; SURVEY 8e)
+        n_streams = max(1, min(args.streams, len(batches)))
+        comps = [wah.DeviceCompressor(widest * n if batched else n, device=dev, indexed=batched) for _ in range(n_streams)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
+        sizes = torch.zeros(max(len(batches), 1), dtype=torch.int64, device=dev)  # C of every launch, written by the kernels
+
+        def launch(i, b, row, comp, st):
+            rows = matrix[row:row + len(b)]
+            if batched:
+                # ONE launch per batch: whole 992-word segments, so the result is the columns' streams back to back;
+                # the segment index gives the column boundaries
+                comp.run(rows.view(-1), n_words=rows.numel(), stream=st, count=sizes[i:i + 1])
+            else:
+                comp.run(rows[0], stream=st, count=sizes[i:i + 1])
+
+        def step():
+            row = 0
+            main = torch.cuda.current_stream(dev)
+            for st in streams:
+                if st is not None:
+                    st.wait_stream(main)
+            for i, b in enumerate(batches):
+                launch(i, b, row, comps[i % n_streams], streams[i % n_streams])
+                row += len(b)
+            for st in streams:
+                if st is not None:
+                    main.wait_stream(st)
+
+        # every launch once, on its own, with its status read back: an error of ANY launch is seen (inside the timed
+        # loop a later launch on the same compressor starts by clearing the error word), and its time is the kernel's
+        row, ev_ms = 0, []
+        for i, b in enumerate(batches):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            ev[0].record()
+            launch(i, b, row, comps[i % n_streams], None)
+            ev[1].record()
+            torch.cuda.synchronize(dev)
+            comps[i % n_streams].status()
+            ev_ms.append(ev[0].elapsed_time(ev[1]))
+            row += len(b)
+        one_stream_ms = sum(ev_ms) / max(len(ev_ms), 1)
+        c_words_rank = float(sizes.sum().item())
+    elapsed = timed_steps(step, steps, warmup, dist, dev)
+    if not cpu_only:
+        for comp in comps:
+            comp.status()
+    stats = torch.tensor([4.0 * n * len(mine), c_words_rank], dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(stats)
+    if rank != 0:
+        return None
+    in_bytes_job, c_words_job = float(stats[0].item()), float(stats[1].item())
+    algo = in_bytes_job + 4.0 * c_words_job  # compress: read N, write C, all columns
+    achieved = steps * algo / elapsed / 1e9
+    return {
+        "metric": "compress GB/s (input bits), 1024 independent 128 MiB bitmap columns",
+        "value": round(steps * in_bytes_job / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": desc, "words_per_column": n, "columns": n_columns,
+                   "columns_per_gpu": len(mine), "seed": args.seed, "launches_per_step": len(batches),
+                   "columns_per_launch": max((len(b) for b in batches), default=0),
+                   "streams": n_streams,
+                   "outputs": "every launch writes its stream into its HIP stream's output buffer (one per stream, reused by "
+                              "the next launch on it): compressor throughput, nothing consumes the compressed columns",
+                   "parallelism": f"column-shard x{world}, no collective"},
+        "compression_ratio_C_over_N": round(c_words_job * 4.0 / in_bytes_job, 6) if in_bytes_job else None,
+        "roofline": {"kernel": "compress_pair_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS * world,
+                     "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_GBPS * world), 4), "traffic": None,
+                     "algorithmic_bytes_per_step": algo,
+                     "note": "(4N + 4C) of all columns / wall time of the step, whole job against N x 8 TB/s; the launches of a "
+                             "step overlap on the streams, so this is not one launch's duration",
+                     "launch_ms_alone": round(one_stream_ms, 4) if one_stream_ms is not None else None,
+                     "frac_launch_alone": (round(algo / max(len(batches), 1) / world / (one_stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                                           if one_stream_ms else None)},
+    }
+
+
 def init_ranks(rank, world):
     """Control plane of an N > 1 run: gloo on 127.0.0.1 (barriers + two scalars).  RCCL is not used."""
     import torch.distributed as dist
@@ -246,74 +355,8 @@ def run_rank(args):
 
     # ---- independent columns: compress only, fixed total -----------------------------------------------------------
     if args.workload == "columns":
-        n = args.words or COLUMN_WORDS
-        n_columns = args.columns or COLUMNS_TOTAL
-        mine, batches = column_plan(n_columns, rank, world, 1 if args.per_column_launches else args.columns_per_launch)
-        c_words_rank = 0.0
-        if cpu_only:
-            def step():
-                pass
-        else:
-            wah = importlib.import_module("gpu-wah_amd")
-            wah.lib()
-            specs = [wah.columns.column_spec(c, n, args.seed) for c in mine]
-            batched = n % wah.columns.SEGMENT_WORDS == 0 and not args.per_column_launches
-            # all of the rank's columns stay resident: one [columns, n] matrix, generated once
-            matrix = wah.columns.make_column_matrix(wah, specs, dev) if specs else None
-            widest = max((len(b) for b in batches), default=1)
-            # the launches go round robin over a few streams, each with its own compressor (output buffer + workspace):
-            # the tail of one launch overlaps the start of the next ("just per-GPU streams", north_star)
-            n_streams = max(1, min(args.streams, len(batches)))
-            comps = [wah.DeviceCompressor(widest * n if batched else n, device=dev, indexed=batched) for _ in range(n_streams)]
-            streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [None]
-            sizes = torch.zeros(max(len(batches), 1), dtype=torch.int64, device=dev) # C of every launch, written by the kernels
-
-            def step():
-                row = 0
-                main = torch.cuda.current_stream(dev)
-                for st in streams:
-                    if st is not None:
-                        st.wait_stream(main)
-                for i, b in enumerate(batches):
-                    rows = matrix[row:row + len(b)]
-                    comp, st = comps[i % n_streams], streams[i % n_streams]
-                    if batched:
-                        # ONE launch per batch: whole 992-word segments, so the result is the columns' streams back to
-                        # back; the segment index gives the column boundaries
-                        comp.run(rows.view(-1), n_words=rows.numel(), stream=st, count=sizes[i:i + 1])
-                    else:
-                        comp.run(rows[0], stream=st, count=sizes[i:i + 1])
-                    row += len(b)
-                for st in streams:
-                    if st is not None:
-                        main.wait_stream(st)
-
-            step()
-            torch.cuda.synchronize(dev)
-            for comp in comps:
-                comp.status()
-            c_words_rank = float(sizes.sum().item())
-        elapsed = timed_steps(step, args.steps, args.warmup, dist, dev)
-        if not cpu_only:
-            for comp in comps:
-                comp.status()
-        stats = torch.tensor([4.0 * n * len(mine), c_words_rank], dtype=torch.float64)
-        if dist is not None:
-            dist.all_reduce(stats)
+        out = columns_measurement(args, dev, rank, world, dist, cpu_only, args.steps, args.warmup, desc)
         if rank == 0:
-            in_bytes_job, c_words_job = float(stats[0].item()), float(stats[1].item())
-            out = {
-                "metric": "compress GB/s (input bits), 1024 independent 128 MiB bitmap columns",
-                "value": round(args.steps * in_bytes_job / elapsed / 1e9, 3), "unit": "GB/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-                "config": {"workload": desc, "words_per_column": n, "columns": n_columns,
-                           "columns_per_gpu": len(mine), "seed": args.seed, "launches_per_step": len(batches),
-                           "columns_per_launch": max((len(b) for b in batches), default=0),
-                           "streams": 1 if cpu_only else n_streams,
-                           "parallelism": f"column-shard x{world}, no collective"},
-                "compression_ratio_C_over_N": round(c_words_job * 4.0 / in_bytes_job, 6) if in_bytes_job else None,
-            }
             out.update(extra)
             print(json.dumps(out), flush=True)
         finish()
@@ -463,7 +506,7 @@ def run_rank(args):
             "decompress_ms": {"avg": round(dec_avg, 4), "min": round(dec_ms[0], 4), "median": round(dec_ms[len(dec_ms) // 2], 4)},
             "copy_ceiling_GBps": round(copy_gbps, 1),
             "two_round_trips_in_flight_GBps": round(two_in_flight, 1) if two_in_flight else None,
-            "roofline": {"kernel": "compress_tile_kernel", "bound": "hbm", "achieved": round(achieved, 1),
+            "roofline": {"kernel": "compress_pair_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                          "traffic": tr.get("compress_bytes_per_launch"), "traffic_measured_in_run": False,
                          "traffic_source": tr.get("source"),
@@ -488,6 +531,16 @@ def run_rank(args):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, param, args.cpu_sample_mib, args.seed)
         out.update(extra)
+    # side block, never `value`: BASELINE configs[4] -- the 1024 independent 128 MiB columns, column c on rank c mod N --
+    # so that the default command (the one the driver runs at N = 1, 2, 4, 8) also carries the column-shard figure
+    if not args.no_columns:
+        del comp, dec, d_in
+        torch.cuda.empty_cache()
+        side = columns_measurement(args, dev, rank, world, dist, False, args.columns_steps, 1, WORKLOADS["columns"][2])
+        if rank == 0:
+            out["columns"] = {k: side[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "scaling", "config",
+                                                   "compression_ratio_C_over_N", "roofline")}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     finish()
 

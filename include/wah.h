@@ -9,7 +9,11 @@
  * the reference's source.cpp / tests.cpp link against libwah_hip.so unchanged.
  *
  * Units: all sizes are in 32-bit words unless a name says bytes
- * (compress.cu:35-36, decompress.cu:12-13).
+ * (compress.cu:35-36, decompress.cu:12-13).  Sizes, word indices and offsets are
+ * 64-bit throughout; a bitmap or a stream of 2^40 words (4 TiB) or more is
+ * refused with WAH_ERR_ARG (the reference: int indices, dataSize < 2^31,
+ * kernels.cu:51).  Tested on the GPU up to one launch of 4 362 072 000 words
+ * (130 columns of 128 MiB: tests/test_gpu_parity.py).
  *
  * Wire format (reference const.h:3-16, kernels.cu:79,244-249,298-354):
  * 31-bit groups of the LSB-first bit stream; literal = group (bit31 = 0);
@@ -98,8 +102,10 @@ size_t wah_decompress_workspace_bytes(uint64_t c_words, uint64_t out_capacity_wo
  * then keeps itself up: every launch stamps what it leaves there with a launch epoch, so nothing is cleared between
  * launches, and one workspace may serve inputs of different sizes (up to the one it was sized for) in turn -- but only
  * one launch at a time.  A workspace that is neither zeroed nor left by an earlier launch is reported as
- * WAH_ERR_WORKSPACE by the status calls.  (The `scratch` of the wah_bitop_* calls needs no initialisation.)
- * Asynchronous on `stream`. */
+ * WAH_ERR_WORKSPACE by the status calls (checked: the magic word, the launch epoch, and every tile number drawn from
+ * the ticket counter, before anything is indexed with it).  Where a launch keeps its entries depends on the workspace's
+ * size only, so pass the SAME workspace_bytes with a workspace every time.  (The `scratch` of the wah_bitop_* calls
+ * needs no initialisation.)  Asynchronous on `stream`. */
 int wah_workspace_init_device(void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* d_in: n_words words, 16-byte aligned.  d_out: room for out_capacity_words

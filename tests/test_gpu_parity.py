@@ -1019,6 +1019,51 @@ def _indexed_stream(wah, d_in):
     return comp.result().clone(), comp.seg_offsets.clone()
 
 
+def _check_column_launch(wah, oracle, n_columns, n=33554400, seed=1337):
+    """`n_columns` columns of `n` words (the three bench distributions in turn) compressed in ONE launch, exactly as
+    bench.py's columns workload does it (column matrix resident in HBM, indexed compressor sized for the whole batch).
+    Checked: the column offsets out of the segment index; for one column of each distribution (the first three and the last
+    three columns) the column's stream == compressing that column alone == the oracle on a 1024-segment prefix; the
+    index decode of those columns == the matrix rows.  Returns the number of words of the launch."""
+    import torch
+
+    specs = [wah.columns.column_spec(c, n, seed) for c in range(n_columns)]
+    matrix = wah.columns.make_column_matrix(wah, specs, "cuda:0")
+    comp = wah.DeviceCompressor(matrix.numel(), indexed=True)
+    stream, offs = wah.columns.compress_column_matrix(comp, matrix)
+    offs = offs.cpu().numpy()
+    segs = n // 992
+    assert len(offs) == n_columns + 1 and offs[0] == 0 and offs[-1] == stream.numel() == int(comp.count.item())
+    assert bool(np.all(np.diff(offs) >= segs))  # every segment holds at least one word
+    every = comp.seg_offsets[: n_columns * segs + 1]
+    assert bool((every[1:] > every[:-1]).all())
+    one = wah.DeviceCompressor(n)
+    prefix = 992 * 1024
+    for c in sorted(set(list(range(min(3, n_columns))) + list(range(max(n_columns - 3, 0), n_columns)))):
+        one.run(matrix[c])
+        alone = one.result()
+        mine = stream[offs[c]: offs[c + 1]]
+        assert bool(torch.equal(alone, mine)), c
+        want = oracle.compress(_host(matrix[c][:prefix]))
+        assert np.array_equal(_host(mine[: len(want)]), want), c
+        back = wah.decompress_segments_device(stream, comp.seg_offsets, matrix.numel(), first_segment=c * segs, n_segments=segs)
+        assert bool(torch.equal(back, matrix[c])), c
+        del back, alone
+    return matrix.numel()
+
+
+def test_config5_one_launch_at_the_bench_shape(wah, oracle):
+    """BASELINE config 5 at the shape bench.py times: 128 columns x 33 554 400 words = 4 294 963 200 words (16 GiB, 4096
+    words below 2^32) in ONE launch."""
+    assert _check_column_launch(wah, oracle, 128) == 4294963200
+
+
+def test_one_launch_above_2_32_words(wah, oracle):
+    """130 columns = 4 362 072 000 words in one launch: word indices, segment numbers and offsets beyond 32 bits
+    (include/wah.h: n_words < 2^40)."""
+    assert _check_column_launch(wah, oracle, 130, seed=77) > 1 << 32
+
+
 @pytest.mark.parametrize("n", [1, 31, 991, 992, 993, 992 * 3 + 17, 992 * 64, 262144 + 5])
 def test_decode_segments_through_the_index(wah, oracle, n):
     """wah_decompress_segments_device: with the segment index of the indexed compressor every 992-word segment decodes

@@ -1,21 +1,29 @@
 #!/bin/bash
 # Collect the round's profile evidence on the GPU box into gpurun_out/profiles_rNN/ (copy the summaries to profiles/).
 # usage: tools/make_profiles.sh r01
-tag=${1:-r02}
+tag=${1:-r03}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 out=$R/gpurun_out/profiles_$tag
 rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 for wl in sparse clustered dense; do
   # (a) kernel trace + stats of the exact bench command
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$wl -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $wl > $out/bench_profiled_$wl.json 2> $out/kt_$wl.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$wl -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-columns --workload $wl > $out/bench_profiled_$wl.json 2> $out/kt_$wl.err
   # (b) HBM traffic: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --workload $wl > /dev/null 2> $out/pmc_${wl}_$c.err
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-columns --workload $wl > /dev/null 2> $out/pmc_${wl}_$c.err
   done
   # (c) the un-profiled bench line
   python3 $R/bench.py --steps 20 --warmup 3 --workload $wl > $out/bench_$wl.json 2> $out/bench_$wl.err
   echo "done $wl"
+done
+# (d) SQ counters of the three kernels on the headline workload (separate passes: 8 SQ slots per pass), same build, same run
+i=0
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
+           "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_SMEM SQ_INSTS_BRANCH GRBM_GUI_ACTIVE GRBM_COUNT"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/sq_p$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-columns --workload sparse > /dev/null 2> $out/sq_p$i.err || echo "SQ pass $i failed"
 done
 python3 - <<PY
 import csv, glob, json, re, collections, os
@@ -30,7 +38,7 @@ for wl in ("sparse", "clustered", "dense"):
             m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
             k = m.group(1) if m else r["Kernel_Name"][:48]
             d[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    lines.append(f"== {wl}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload {wl}")
+    lines.append(f"== {wl}: rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-columns --workload {wl}")
     for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):
         lines.append(f"  {k:36s} calls {len(v):4d}  avg {sum(v)/len(v):10.1f} us  min {min(v):10.1f}  max {max(v):10.1f}  total {sum(v):12.1f}")
     # PMC: bytes per launch
@@ -50,7 +58,7 @@ for wl in ("sparse", "clustered", "dense"):
         t = tr.get(k, {})
         return (2.0 * t.get("FETCH_SIZE", 0) + t.get("WRITE_SIZE", 0)) * 1024.0
     summary[wl] = {
-        "compress_bytes_per_launch": hbm("compress_tile_kernel"),
+        "compress_bytes_per_launch": hbm("compress_pair_kernel"),
         "decompress_bytes_per_launch": hbm("decode_sums_kernel") + hbm("decode_expand_kernel"),
         "decompress_indexed_bytes_per_launch": hbm("decode_segments_kernel"),
         "source": f"profiles/{os.path.basename(out).replace('profiles_', '')}_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md",
@@ -60,6 +68,40 @@ for wl in ("sparse", "clustered", "dense"):
         lines.append("  bench line: " + open(f"{out}/bench_{wl}.json").read().strip())
     except Exception:
         pass
+# SQ counters, mean per dispatch, the three kernels of the round trip (sparse)
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{out}/sq_p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"(compress_pair_kernel|decode_sums_kernel|decode_expand_kernel)", r["Kernel_Name"])
+        if m:
+            agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(f"{out}/pmc_sq_counters_sparse.txt", "w") as o:
+    o.write("rocprofv3 --kernel-trace --pmc <8 SQ counters per pass> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-columns --workload sparse\n")
+    for k in agg:
+        o.write(f"== {k}\n")
+        for c, v in sorted(agg[k].items()):
+            o.write(f"  {c:28s} mean/dispatch {sum(v)/len(v):16.1f}  (n={len(v)})\n")
+    c = agg.get("compress_pair_kernel", {})
+    if c.get("SQ_INSTS_VALU") and c.get("GRBM_GUI_ACTIVE"):
+        mean = lambda k: sum(c[k]) / len(c[k])
+        segs = 270600.0
+        cycles = mean("GRBM_GUI_ACTIVE") / 8.0  # the counter sums the 8 XCDs
+        o.write(f"== compress_pair_kernel, derived (1 GiB = {int(segs)} segments, 1024 SIMDs)\n")
+        o.write(f"  instructions per segment: vector {mean('SQ_INSTS_VALU')/segs:.0f}, scalar {mean('SQ_INSTS_SALU')/segs:.0f}, LDS {mean('SQ_INSTS_LDS')/segs:.0f}, "
+                f"branch {mean('SQ_INSTS_BRANCH')/segs if c.get('SQ_INSTS_BRANCH') else 0:.0f}, vector memory {(mean('SQ_INSTS_VMEM_RD')+mean('SQ_INSTS_VMEM_WR'))/segs:.1f}\n")
+        o.write(f"  kernel cycles (GRBM_GUI_ACTIVE / 8): {cycles:.0f}\n")
+        per_simd = mean("SQ_INSTS_VALU") / 1024.0
+        o.write(f"  vector instructions per SIMD: {per_simd:.0f}; VALU pipe busy at 2 cycles per wave64 instruction (SIMD-32): {2*per_simd/cycles:.2f}, "
+                f"at the 4 cycles one wave alone needs per instruction: {4*per_simd/cycles:.2f}\n")
+        if c.get("SQ_WAVE_CYCLES"):
+            o.write(f"  of the wave cycles: issuing {mean('SQ_ACTIVE_INST_ANY')/mean('SQ_WAVE_CYCLES'):.2f}, issue-stalled {mean('SQ_WAIT_INST_ANY')/mean('SQ_WAVE_CYCLES'):.2f}, "
+                    f"waiting (s_waitcnt / barrier) {mean('SQ_WAIT_ANY')/mean('SQ_WAVE_CYCLES'):.2f}\n")
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            o.write(f"  LDS bank conflict cycles / LDS active cycles: {mean('SQ_LDS_BANK_CONFLICT')/mean('SQ_LDS_IDX_ACTIVE'):.2f}\n")
+    e = agg.get("decode_expand_kernel", {})
+    if e.get("SQ_LDS_IDX_ACTIVE"):
+        o.write(f"== decode_expand_kernel: LDS bank conflict cycles / LDS active cycles: {sum(e['SQ_LDS_BANK_CONFLICT'])/len(e['SQ_LDS_BANK_CONFLICT'])/(sum(e['SQ_LDS_IDX_ACTIVE'])/len(e['SQ_LDS_IDX_ACTIVE'])):.2f}\n")
+print(open(f"{out}/pmc_sq_counters_sparse.txt").read())
 open(f"{out}/summary.txt", "w").write("\n".join(lines) + "\n")
 json.dump(summary, open(f"{out}/traffic.json", "w"), indent=1)
 print("\n".join(lines))
