@@ -16,8 +16,12 @@
 #include <cstdlib>
 #include <cstring>
 
+// (-fvisibility=hidden: the reference's two entry points are exported like everything include/wah.h declares; their
+//  headers stay the reference's text)
+#pragma GCC visibility push(default)
 #include "../../include/compress.h"
 #include "../../include/decompress.h"
+#pragma GCC visibility pop
 #include "../../include/wah.h"
 #include "wah_internal.hpp"
 

@@ -1154,8 +1154,9 @@ __device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
     }
 }
 
+// (two segments per wave need 90 registers: held to the 80 of six waves per SIMD the kernel spilled 18 of them)
 template <bool kAligned, u32 kWaveSegs>
-__global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compress_unseg_kernel(const CompressArgs a) {
+__global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 1 ? 6 : 4) void compress_unseg_kernel(const CompressArgs a) {
     compress_unseg_body<kAligned, kWaveSegs>(a);
 }
 

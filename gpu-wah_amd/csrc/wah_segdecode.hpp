@@ -16,14 +16,15 @@ constexpr int kSegBatches = kSegGroups / 128;
 struct SegRange {
     u64 w0;
     u32 cnt, nvalid;
-    bool bad;
+    u32 bad, spare; // (no padding bytes: a copy of the struct stays in registers instead of going through scratch)
 };
 __device__ __forceinline__ SegRange seg_range(const SegmentsArgs &a, u64 seg, u64 w0, u64 w1) {
     SegRange r;
     const u64 g0 = seg * kSegGroups;
     r.nvalid = a.groups - g0 < kSegGroups ? (u32)(a.groups - g0) : kSegGroups;
     // every word of a compress() stream covers at least one group
-    r.bad = w1 < w0 || w1 > a.c_words || w1 - w0 > r.nvalid;
+    r.bad = (w1 < w0 || w1 > a.c_words || w1 - w0 > r.nvalid) ? 1u : 0u;
+    r.spare = 0;
     r.cnt = r.bad ? 0u : (u32)(w1 - w0);
     r.w0 = w0;
     return r;

@@ -29,6 +29,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: what this header declares (and the reference's two C++ symbols of
+ * compress.h / decompress.h) is ALL it exports (tests/test_abi.py checks the dynamic symbol table) */
+#pragma GCC visibility push(default)
 
 #define WAH_SEGMENT_WORDS 992u   /* compress.cu:62  blockCount = dataSize / (31*32) */
 #define WAH_SEGMENT_GROUPS 1024u /* kernels.cu:68   one (32,32) CUDA block          */
@@ -287,6 +290,7 @@ const char *wah_last_error(void);
 /* Library / build identification, e.g. "wah-mi355x 0.1 gfx950". */
 const char *wah_version(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

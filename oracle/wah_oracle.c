@@ -114,69 +114,129 @@ uint64_t wah_oracle_compress(const uint32_t *in, uint64_t n_words, uint32_t *out
  * page faults on the second copy of the output, not arithmetic, set the pace.) */
 typedef struct {
     const uint32_t *in;
-    uint64_t n_words, seg_lo, seg_hi;
+    uint64_t n_words, seg_lo, seg_hi, count, offset;
     uint32_t *out;
-    uint64_t count, offset;
-    pthread_barrier_t *counted, *placed;
-    void *all;
-    int index, threads;
 } mt_job;
 
+/* A persistent pool: the workers are created once and parked on a barrier between calls.  (Creating 256 threads per
+ * call cost as much as the compression itself and made the all-cores figure swing 11 .. 38 GB/s between two boxes of the
+ * same CPU.)  Three barriers per call: start (jobs are set), counted (every job's word count is known -- thread 0 turns
+ * them into offsets), done.  The caller takes part in start and done. */
+static struct {
+    pthread_t *tid;
+    mt_job *jobs;
+    int threads;          /* workers in the pool (0: none) */
+    int wanted;           /* ... and how many were asked for */
+    pthread_barrier_t start, counted, done;
+    volatile int quit;
+} g_pool;
+
+static pthread_mutex_t g_gate_m = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_gate_c = PTHREAD_COND_INITIALIZER;
+static int g_gate_open; /* set once the barriers are sized for the workers that actually started */
+
 static void *mt_worker(void *p) {
-    mt_job *j = (mt_job *)p;
+    const int index = (int)(intptr_t)p;
     uint32_t one[WAH_O_SEG_GROUPS + 1]; /* a segment emits at most 1024 words */
-    j->count = 0;
-    for (uint64_t s = j->seg_lo; s < j->seg_hi; ++s) j->count += compress_segments(j->in, j->n_words, s, s + 1, one);
-    pthread_barrier_wait(j->counted);
-    if (j->index == 0) {
-        mt_job *all = (mt_job *)j->all;
-        uint64_t c = 0;
-        for (int t = 0; t < j->threads; ++t) {
-            all[t].offset = c;
-            c += all[t].count;
+    pthread_mutex_lock(&g_gate_m);
+    while (!g_gate_open) pthread_cond_wait(&g_gate_c, &g_gate_m);
+    pthread_mutex_unlock(&g_gate_m);
+    for (;;) {
+        pthread_barrier_wait(&g_pool.start);
+        if (g_pool.quit) return NULL;
+        mt_job *j = &g_pool.jobs[index];
+        j->count = 0;
+        for (uint64_t s = j->seg_lo; s < j->seg_hi; ++s) j->count += compress_segments(j->in, j->n_words, s, s + 1, one);
+        pthread_barrier_wait(&g_pool.counted);
+        if (index == 0) {
+            uint64_t c = 0;
+            for (int t = 0; t < g_pool.threads; ++t) {
+                g_pool.jobs[t].offset = c;
+                c += g_pool.jobs[t].count;
+            }
         }
+        pthread_barrier_wait(&g_pool.counted);
+        (void)compress_segments(j->in, j->n_words, j->seg_lo, j->seg_hi, j->out + j->offset);
+        pthread_barrier_wait(&g_pool.done);
     }
-    pthread_barrier_wait(j->placed);
-    (void)compress_segments(j->in, j->n_words, j->seg_lo, j->seg_hi, j->out + j->offset);
-    return NULL;
 }
+
+static void pool_stop(void) {
+    if (!g_pool.threads) return;
+    g_pool.quit = 1;
+    pthread_barrier_wait(&g_pool.start);
+    for (int t = 0; t < g_pool.threads; ++t) pthread_join(g_pool.tid[t], NULL);
+    pthread_barrier_destroy(&g_pool.start);
+    pthread_barrier_destroy(&g_pool.counted);
+    pthread_barrier_destroy(&g_pool.done);
+    free(g_pool.tid);
+    free(g_pool.jobs);
+    g_pool.tid = NULL;
+    g_pool.jobs = NULL;
+    g_pool.threads = 0;
+    g_pool.quit = 0;
+    g_gate_open = 0;
+}
+
+/* A pool of up to `threads` workers; returns how many there are (a thread that fails to start is simply not counted:
+ * the barriers are sized for the ones that did, 0 = none). */
+static int pool_start(int threads) {
+    if (g_pool.threads && g_pool.wanted == threads) return g_pool.threads;
+    pool_stop();
+    g_pool.tid = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
+    g_pool.jobs = (mt_job *)calloc((size_t)threads, sizeof(mt_job));
+    if (!g_pool.tid || !g_pool.jobs) {
+        free(g_pool.tid);
+        free(g_pool.jobs);
+        g_pool.tid = NULL;
+        g_pool.jobs = NULL;
+        return 0;
+    }
+    int started = 0;
+    for (; started < threads; ++started)
+        if (pthread_create(&g_pool.tid[started], NULL, mt_worker, (void *)(intptr_t)started) != 0) break;
+    if (started == 0) {
+        free(g_pool.tid);
+        free(g_pool.jobs);
+        g_pool.tid = NULL;
+        g_pool.jobs = NULL;
+        return 0;
+    }
+    pthread_barrier_init(&g_pool.start, NULL, (unsigned)started + 1u);
+    pthread_barrier_init(&g_pool.counted, NULL, (unsigned)started);
+    pthread_barrier_init(&g_pool.done, NULL, (unsigned)started + 1u);
+    g_pool.threads = started;
+    g_pool.wanted = threads;
+    pthread_mutex_lock(&g_gate_m);
+    g_gate_open = 1;
+    pthread_cond_broadcast(&g_gate_c);
+    pthread_mutex_unlock(&g_gate_m);
+    return started;
+}
+
+void wah_oracle_pool_release(void) { pool_stop(); }
 
 uint64_t wah_oracle_compress_mt(const uint32_t *in, uint64_t n_words, uint32_t *out, int threads) {
     const uint64_t nseg = segment_count(n_words);
     if (threads < 1) threads = 1;
     if ((uint64_t)threads > nseg) threads = nseg ? (int)nseg : 1;
-    if (threads == 1) return wah_oracle_compress(in, n_words, out);
-    mt_job *jobs = (mt_job *)calloc((size_t)threads, sizeof(mt_job));
-    pthread_t *tid = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
-    pthread_barrier_t counted, placed;
-    pthread_barrier_init(&counted, NULL, (unsigned)threads);
-    pthread_barrier_init(&placed, NULL, (unsigned)threads);
+    if (threads > 1) threads = pool_start(threads);
+    if (threads <= 1) return wah_oracle_compress(in, n_words, out);
     const uint64_t per = (nseg + threads - 1) / threads;
     for (int t = 0; t < threads; ++t) {
         uint64_t lo = per * t, hi = lo + per;
         if (lo > nseg) lo = nseg;
         if (hi > nseg) hi = nseg;
-        jobs[t].in = in;
-        jobs[t].n_words = n_words;
-        jobs[t].seg_lo = lo;
-        jobs[t].seg_hi = hi;
-        jobs[t].out = out;
-        jobs[t].counted = &counted;
-        jobs[t].placed = &placed;
-        jobs[t].all = jobs;
-        jobs[t].index = t;
-        jobs[t].threads = threads;
-        pthread_create(&tid[t], NULL, mt_worker, &jobs[t]);
+        g_pool.jobs[t].in = in;
+        g_pool.jobs[t].n_words = n_words;
+        g_pool.jobs[t].seg_lo = lo;
+        g_pool.jobs[t].seg_hi = hi;
+        g_pool.jobs[t].out = out;
     }
+    pthread_barrier_wait(&g_pool.start);
+    pthread_barrier_wait(&g_pool.done);
     uint64_t c = 0;
-    for (int t = 0; t < threads; ++t) {
-        pthread_join(tid[t], NULL);
-        c += jobs[t].count;
-    }
-    pthread_barrier_destroy(&counted);
-    pthread_barrier_destroy(&placed);
-    free(jobs);
-    free(tid);
+    for (int t = 0; t < threads; ++t) c += g_pool.jobs[t].count;
     return c;
 }
 

@@ -54,6 +54,7 @@ uint64_t wah_oracle_compress(const uint32_t *in, uint64_t n_words, uint32_t *out
  * independent by F4).  Bit-identical output.  Used as the multi-core CPU
  * baseline only. */
 uint64_t wah_oracle_compress_mt(const uint32_t *in, uint64_t n_words, uint32_t *out, int threads);
+void wah_oracle_pool_release(void); /* joins the worker threads wah_oracle_compress_mt keeps between calls */
 
 /* Number of 31-bit groups a compressed stream expands to (getCounts,
  * kernels.cu:291-309 + the scan at decompress.cu:72-82). */

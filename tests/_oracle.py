@@ -115,7 +115,7 @@ class Oracle:
         back = np.zeros(a.size + 2, np.uint32)
         back.fill(1)
         best_c = best_d = float("inf")
-        for _ in range(reps):
+        for _ in range(reps + (1 if threads > 1 else 0)):  # (the first multi-threaded call starts the pool's threads)
             t0 = time.perf_counter()
             if threads > 1:
                 c = int(self.lib.wah_oracle_compress_mt(_ptr(a), a.size, _ptr(out), int(threads)))

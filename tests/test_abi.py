@@ -35,6 +35,15 @@ def test_reference_cxx_symbols_exported(pkg):
         assert re.search(rf"\bT {sym}\b", out), sym
 
 
+def test_nothing_else_is_exported(pkg):
+    """The dynamic symbol table holds the extern "C" ABI of include/wah.h and the reference's two C++ entry points --
+    no launcher, no layout helper, no kernel stub, no template instantiation of the C++ runtime (exports.map)."""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pkg.lib_path()], text=True)
+    names = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    allowed = set(pkg.ABI_SYMBOLS) | {"_Z8compressPjyPyPfS1_S1_", "_Z10decompressPjyPyPfS1_S1_"}
+    assert names == allowed, sorted(names ^ allowed)
+
+
 def test_size_helpers_match_reference_formulas(pkg, oracle):
     lib = pkg.lib()
     for n in (0, 1, 30, 31, 32, 992, 993, 262144, 268435200, 268435456):
