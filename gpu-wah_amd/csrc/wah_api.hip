@@ -448,11 +448,13 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     a.unseg_desc = nullptr;
     a.pair_layout = 0;
     if (!d_in2 && !indexed && !unsegmented && !no_wait) { // the plain compress: pair-layout kernel, its own tile shape
-        const uint32_t pairs = wah::compress_wave_pairs(l.n_segments);
-        if (pairs) {
+        const wah::TileShape shape = wah::compress_tile_shape(l.n_segments);
+        if (shape.body_pairs) {
             a.pair_layout = 1;
-            a.wave_segs = 2 * pairs;
-            a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
+            a.wave_segs = 2 * shape.body_pairs;
+            a.tail_pairs = shape.tail_pairs;
+            a.big_tiles = shape.big_tiles;
+            a.n_tiles = shape.n_tiles;
         }
     }
     if (unsegmented) { // fills cross the segment cut (compress_unseg_kernel): its own scan area, at most 4 segments per wave

@@ -1233,7 +1233,13 @@ __global__ __launch_bounds__(kTileWaves * 64, 4) void compress_tile_pair_nowait_
 constexpr u32 kNoWaitWaveSegs = 4;
 template <bool kAligned, int kMode>
 __global__ __launch_bounds__(kTileWaves * 64, 4) void compress_nowait_kernel(const CompressArgs a) {
-    compress_pair_body<kAligned, kNoWaitWaveSegs / 2, kMode>(a);
+    __shared__ __attribute__((aligned(16))) u32 s_stage[kTileWaves][kPairStageWords];
+    __shared__ u32 s_count[kTileWaves];
+    __shared__ u32 s_prefix[kTileWaves];
+    __shared__ u64 s_base;
+    const PairShared sm = {s_stage, s_count, s_prefix, &s_base};
+    const LaunchEpoch le = {};
+    compress_pair_body<kAligned, kNoWaitWaveSegs / 2, kMode>(a, sm, blockIdx.x, blockIdx.x * (kTileWaves * (kNoWaitWaveSegs / 2)), le);
 }
 
 // counts of the tiles -> where every tile's words start (exclusive scan, in place), + everything the last tile of the
@@ -1350,11 +1356,17 @@ hipError_t launch_compress_nowait(const CompressArgs &a, hipStream_t s) {
 template <bool kAligned>
 static void launch_pairs(const CompressArgs &a, hipStream_t s) {
     const dim3 grid(a.n_tiles), block(kTileWaves * 64);
-    switch (a.wave_segs) {
-    case 2: hipLaunchKernelGGL((compress_pair_kernel<kAligned, 1>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((compress_pair_kernel<kAligned, 2>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((compress_pair_kernel<kAligned, 3>), grid, block, 0, s, a); break;
-    }
+    const u32 body = a.wave_segs / 2, tail = a.tail_pairs;
+    if (body == 3 && tail == 1)
+        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 3, 1>), grid, block, 0, s, a);
+    else if (body == 3 && tail == 2)
+        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 3, 2>), grid, block, 0, s, a);
+    else if (body == 3)
+        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 3, 3>), grid, block, 0, s, a);
+    else if (body == 2)
+        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 2, 2>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((compress_pair_kernel<kAligned, 1, 1>), grid, block, 0, s, a);
 }
 
 hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {
@@ -1407,17 +1419,50 @@ uint32_t compress_wave_segs(uint64_t n_segments) {
     return (uint32_t)kCompressMaxWaveSegs;
 }
 
-// pair-layout kernel (compress_pair_kernel): pairs of segments per wavefront
-uint32_t compress_wave_pairs(uint64_t n_segments) {
-    static const int forced = [] { // experiments only: 0 switches the kernel off
+// pair-layout kernel (compress_pair_kernel): the tile shapes of a launch.  A tile is one workgroup's work; the chip runs
+// `slots` of them at a time (two workgroups per CU: LDS).  Whole rounds of the slots are filled with BODY tiles of three
+// pairs per wave (48 segments); what is left over gets the smallest shape -- one, two or three pairs per wave -- that puts
+// it into ONE more round, so that a launch does not end with a few full-size tiles running alone.  Bitmaps of less than a
+// round: one shape, the smallest that fits them into one round.
+TileShape compress_tile_shape(uint64_t n_segments) {
+    static const int forced = [] { // experiments only: 0 switches the kernel off, 1..3: one shape
         const char *e = std::getenv("WAH_WAVE_PAIRS");
         return e ? std::atoi(e) : -1;
     }();
-    if (forced >= 0 && forced <= 3) return (uint32_t)forced;
-    // measured on 1 MiB .. 1 GiB bitmaps (tools/scratch/pair_sizes.py)
-    if (n_segments <= 2400) return 1;
-    if (n_segments <= 6000) return 2;
-    return 3;
+    static const uint64_t slots = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        return (uint64_t)cus * 2u;
+    }();
+    const uint64_t pairs = (n_segments + 1) / 2;
+    const uint64_t w = (uint64_t)kTileWaves;
+    TileShape t = {3, 3, 0, 0};
+    if (forced == 0) return TileShape{0, 0, 0, 0};
+    if (forced >= 1 && forced <= 3) {
+        t.body_pairs = t.tail_pairs = (uint32_t)forced;
+        t.big_tiles = t.n_tiles = (uint32_t)((pairs + w * forced - 1) / (w * forced));
+        return t;
+    }
+    auto fits = [&](uint64_t rest) -> uint32_t { // smallest shape that puts `rest` pairs into one round (3: whatever it takes)
+        return rest <= slots * w ? 1u : rest <= slots * w * 2 ? 2u : 3u;
+    };
+    const uint64_t round = slots * w * 3; // pairs of a full round of body tiles
+    const uint64_t rounds = pairs / round;
+    const uint64_t rest = pairs - rounds * round;
+    if (rounds == 0 || rest == 0) { // one shape.  Less than a round: measured (sparse, tools/scratch/pair_sizes.py; 1 / 2 / 3 pairs
+        // per wave): 8 MiB 8.4 / 10.0 / 12.1 us, 16 MiB 12.3 / 11.5 / 13.3, 32 MiB 22.4 / 18.4 / 16.1, 64 MiB 36.1 / 32.4 / 26.6 --
+        // few long tiles beat many short ones as soon as the bitmap is worth more than the launch's latency chain
+        const uint32_t p = rounds == 0 ? (pairs <= 1400 ? 1u : pairs <= 3000 ? 2u : 3u) : 3u;
+        t.body_pairs = t.tail_pairs = p;
+        t.big_tiles = t.n_tiles = (uint32_t)((pairs + w * p - 1) / (w * p));
+        return t;
+    }
+    t.tail_pairs = fits(rest);
+    t.big_tiles = (uint32_t)(rounds * slots);
+    t.n_tiles = t.big_tiles + (uint32_t)((rest + w * t.tail_pairs - 1) / (w * t.tail_pairs));
+    if (t.tail_pairs == 3) t.big_tiles = t.n_tiles;
+    return t;
 }
 
 // wah_bitop_device: both operands must have expanded to the bitmap length the caller named, without errors of their own

@@ -46,7 +46,12 @@ constexpr uint32_t kEpochWrap = (1u << 16) - 1u;  // stored epoch >= this: the n
 constexpr int kCompressTileWaves = WAH_TILE_WAVES;
 constexpr int kCompressMaxWaveSegs = 5; // segments a wavefront compresses one after the other: 1, 2 or this (by bitmap size)
 uint32_t compress_wave_segs(uint64_t n_segments);
-uint32_t compress_wave_pairs(uint64_t n_segments); // pair-layout kernel: pairs of segments per wavefront (0: kernel switched off)
+// pair-layout kernel: the tile shapes of a launch (compress_pair_kernel): body tiles of body_pairs pairs per wavefront, then
+// tail tiles of tail_pairs; body_pairs == 0: kernel switched off
+struct TileShape {
+    uint32_t body_pairs, tail_pairs, big_tiles, n_tiles;
+};
+TileShape compress_tile_shape(uint64_t n_segments);
 // scan area of the compress kernel (see compress_tile_kernel): one block per superrow of 64 rows x 256 tiles
 constexpr uint32_t kRowSlots = 65;                 // u64 slots of a superrow: words in front of it, words of each of its rows
 constexpr uint32_t kScanSlotsAt = 64 * 256;        // 32-bit words: the slots follow the superrow's granules
@@ -75,7 +80,9 @@ struct CompressArgs {
     uint32_t n_segments;          // ceil(G / 1024)
     uint32_t wave_segs;           // segments per wavefront of this launch (compress_wave_segs)
     uint32_t pair_layout;         // 1: compress_pair_kernel (a lane owns 32 consecutive groups; wave_segs / 2 pairs per wavefront)
-    uint32_t n_tiles;             // ceil(n_segments / (kCompressTileWaves * wave_segs))
+    uint32_t n_tiles;             // ceil(n_segments / (kCompressTileWaves * wave_segs)); pair layout: body + tail tiles
+    uint32_t big_tiles;           // pair layout: tiles [0, big_tiles) have wave_segs / 2 pairs per wave, the rest tail_pairs
+    uint32_t tail_pairs;          // pair layout: pairs per wave of the tail tiles (== wave_segs / 2: one shape)
     uint32_t fast_segments;       // 1: input 16-byte aligned -> prefetched buffer loads; 0: scalar staging
     uint32_t last_segment_groups; // groups of the last segment (1..1024)
     uint32_t full_segments;       // n_words / 992: segments that lie wholly inside the bitmap

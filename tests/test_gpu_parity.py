@@ -1019,6 +1019,28 @@ def _indexed_stream(wah, d_in):
     return comp.result().clone(), comp.seg_offsets.clone()
 
 
+def test_tile_shapes_of_a_launch(wah, oracle):
+    """compress_pair_kernel runs tiles of two shapes in one launch: whole rounds of the chip's 512 workgroup slots as tiles
+    of 48 segments, what is left over as tiles of 16, 32 or 48 segments (compress_tile_shape).  Bitmaps right at the
+    switches between the shapes -- one round = 12 288 pairs of segments, the tail shapes change at 4096 and 8192 pairs
+    left over -- against the oracle, whole streams; the last one with a partial segment at its end."""
+    import torch
+
+    for pairs, extra in ((4096, 0), (4097, 0), (8192, 0), (8193, 0), (12288, 0), (12289, 0), (12288 + 4096, 0), (12288 + 4097, 0),
+                         (12288 + 8193, 0), (2 * 12288 + 5, 0), (12288 + 100, 992 + 17)):
+        n = pairs * 2 * 992 + extra
+        d = wah.gen_uniform_device(n, 1000 + pairs, 0.003)
+        comp = wah.DeviceCompressor(n, indexed=True)
+        comp.run(d)
+        got = _host(comp.result())
+        want = oracle.compress(_host(d))
+        assert np.array_equal(got, want), (pairs, extra)
+        offs = comp.seg_offsets[: (wah.max_compressed_words(n) + 1023) // 1024 + 1]
+        assert int(offs[0]) == 0 and int(offs[-1]) == len(want) and bool((offs[1:] > offs[:-1]).all())
+        del comp, d
+    torch.cuda.synchronize()
+
+
 def _check_column_launch(wah, oracle, n_columns, n=33554400, seed=1337):
     """`n_columns` columns of `n` words (the three bench distributions in turn) compressed in ONE launch, exactly as
     bench.py's columns workload does it (column matrix resident in HBM, indexed compressor sized for the whole batch).
