@@ -1233,7 +1233,7 @@ __global__ __launch_bounds__(kTileWaves * 64, 4) void compress_tile_pair_nowait_
 constexpr u32 kNoWaitWaveSegs = 4;
 template <bool kAligned, int kMode>
 __global__ __launch_bounds__(kTileWaves * 64, 4) void compress_nowait_kernel(const CompressArgs a) {
-    __shared__ __attribute__((aligned(16))) u32 s_stage[kTileWaves][kPairStageWords];
+    __shared__ __attribute__((aligned(1024))) u32 s_stage[kTileWaves][kPairStageWords]; // (the swizzle is made of address bits 7-9)
     __shared__ u32 s_count[kTileWaves];
     __shared__ u32 s_prefix[kTileWaves];
     __shared__ u64 s_base;

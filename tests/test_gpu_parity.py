@@ -118,6 +118,16 @@ def _datasets(oracle, n):
     mix[rng.random(n) < 0.6] = 0
     mix[rng.random(n) < 0.2] = 0xFFFFFFFF
     yield "mixed", mix
+    # lanes with EQUAL word counts (the compress kernel's pass 2 stores those into a swizzled LDS layout):
+    yield "p2^-3", oracle.gen_uniform(n, 1337, 0.125)  # four in ten segment pairs: literals but for a word or two
+    half = oracle.gen_uniform(n, 1337, 0.5)  # every other segment all zeros, the others incompressible
+    half[: n // 992 * 992].reshape(-1, 992)[::2] = 0
+    yield "every other segment dense", half
+    for period in (2, 3, 4, 32):  # one literal group, then period - 1 zero groups
+        bits = np.zeros((32, period, 31), np.uint8)
+        bits[:, 0, ::2] = 1
+        w = np.packbits(bits.reshape(-1), bitorder="little").view(np.uint32)
+        yield f"period {period}", np.tile(w, n // w.size + 1)[:n].copy()
 
 
 def test_distributions_vs_oracle(wah, oracle):

@@ -15,6 +15,19 @@ import torch  # noqa: E402
 
 wah = importlib.import_module("gpu-wah_amd")
 n = 268435200
+
+
+def wall_clock_khz():
+    """The rate of s_memrealtime as the runtime states it (hipDeviceAttributeWallClockRate = 10017)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    v = ctypes.c_int(0)
+    rc = hip.hipDeviceGetAttribute(ctypes.byref(v), 10017, 0)
+    return v.value if rc == 0 else 0
+
+
+khz = wall_clock_khz() or 100000
+print(f"wall clock rate: {khz} kHz")
 tile_segs = 16 * int(os.environ.get("WAH_WAVE_PAIRS", "3"))
 for kind in sys.argv[1:] or ["sparse"]:
     d = {"sparse": lambda: wah.gen_uniform_device(n, 1337, 0.01), "dense": lambda: wah.gen_uniform_device(n, 1337, 0.5),
@@ -22,13 +35,18 @@ for kind in sys.argv[1:] or ["sparse"]:
     comp = wah.DeviceCompressor(n, indexed=True)
     comp.run(d)
     comp.status()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    torch.cuda.synchronize()
+    ev[0].record()
     comp.run(d)
+    ev[1].record()
     comp.status()
+    print(f"--- {kind}: the stamped launch between two events on its stream: {ev[0].elapsed_time(ev[1]) * 1e3:.1f} us")
     n_tiles = (270600 + tile_segs - 1) // tile_segs
     t = comp.seg_offsets[: n_tiles * 8].cpu().numpy().reshape(n_tiles, 8).astype(np.int64)
     start, pub, loaded, done, p1, p2, bar2 = (t[:, i] for i in range(7))
     t0 = start.min()
-    us = lambda x: x / 100.0
+    us = lambda x: x * 1e3 / khz
     q = lambda x: f"{us(x.mean()):.2f} (p10 {us(np.percentile(x, 10)):.2f}, p90 {us(np.percentile(x, 90)):.2f})"
     print(f"--- {kind}: {n_tiles} tiles of {tile_segs} segments, span {us(bar2.max() - t0):.1f} us")
     print(f"   start -> first pair in registers   {q(loaded - start)}")
