@@ -1450,7 +1450,7 @@ TileShape compress_tile_shape(uint64_t n_segments) {
     const uint64_t round = slots * w * 3; // pairs of a full round of body tiles
     const uint64_t rounds = pairs / round;
     const uint64_t rest = pairs - rounds * round;
-    if (rounds == 0 || rest == 0) { // one shape.  Less than a round: measured (sparse, tools/scratch/pair_sizes.py; 1 / 2 / 3 pairs
+    if (rounds == 0 || rest == 0) { // one shape.  Less than a round: measured (sparse, tools/pair_sizes.py; 1 / 2 / 3 pairs
         // per wave): 8 MiB 8.4 / 10.0 / 12.1 us, 16 MiB 12.3 / 11.5 / 13.3, 32 MiB 22.4 / 18.4 / 16.1, 64 MiB 36.1 / 32.4 / 26.6 --
         // few long tiles beat many short ones as soon as the bitmap is worth more than the launch's latency chain
         const uint32_t p = rounds == 0 ? (pairs <= 1400 ? 1u : pairs <= 3000 ? 2u : 3u) : 3u;

@@ -1,6 +1,6 @@
 """Isolated compress launches on the three 1 GiB bench bitmaps: ms per launch, roofline fraction, C and a checksum of the
 stream (to compare builds / kernel variants selected by environment variables across processes).
-usage: python tools/scratch/compress_time.py [size_MiB ...]   (default 1024)"""
+usage: python tools/compress_time.py [size_MiB ...]   (default 1024)"""
 import importlib, os, sys, torch
 sys.path.insert(0, "/root/repo")
 wah = importlib.import_module("gpu-wah_amd")
