@@ -103,6 +103,28 @@ def test_sizes_vs_oracle(wah, oracle, n):
             assert np.array_equal(bd[:n], data), (n, p)
 
 
+@pytest.mark.parametrize("n", [31, 961, 991, 993, 1983, 1984, 1985, 1984 * 3 - 1, 1984 * 3 + 5, 1984 * 8 * 3 + 993, 1984 * 8 * 7 + 17])
+def test_equal_word_counts_per_lane_at_ragged_sizes(wah, oracle, n):
+    """Pairs whose lanes all hold the SAME number of words (literal / zero groups in turn, p = 1/8 noise) go through the
+    swizzled LDS layout of compress_pair_kernel's pass 2; here with the bitmap ending inside a lane, a segment, a pair, a tile."""
+    cases = []
+    for period in (2, 4):
+        bits = np.zeros((32, period, 31), np.uint8)
+        bits[:, 0, ::2] = 1
+        w = np.packbits(bits.reshape(-1), bitorder="little").view(np.uint32)
+        cases.append((f"period {period}", np.tile(w, n // w.size + 1)[:n].copy()))
+    cases.append(("p 1/8", oracle.gen_uniform(n, 11, 0.125)))
+    tail = oracle.gen_uniform(n, 12, 0.5)
+    tail[: n // 2] = 0  # a long fill in front of incompressible words
+    cases.append(("zeros then dense", tail))
+    for name, data in cases:
+        want = oracle.compress(data)
+        got = _host(wah.compress_device(_dev(data)))
+        assert got.shape == want.shape and np.array_equal(got, want), (name, n)
+        back = _host(wah.decompress_device(_dev(want), n + 1))
+        assert np.array_equal(back[:n], data), (name, n)
+
+
 # ---------------------------------------------------------------- distributions
 def _datasets(oracle, n):
     yield "p0.5", oracle.gen_uniform(n, 1337, 0.5)
