@@ -422,11 +422,11 @@ __device__ __forceinline__ u64 tile_scan_resolve(const CompressArgs &a, const Sc
         }
         const u32 n_bad = (u32)__builtin_popcountll(ba) + (u32)__builtin_popcountll(bb) + (u32)__builtin_popcountll(bc);
         if (n_bad <= kDirectLanes) {
-            // a few stragglers among the nearest predecessors (the usual case): read just those lanes' entries again
+            // a few stragglers among the nearest predecessors (the usual case): read again at once, without parking on one word
             __builtin_amdgcn_s_sleep(4);
-            if (need_a && bad_a != 0u) scan_issue(a, g, lane, true, false, false, poll);
-            if (need_b && bad_b != 0u) scan_issue(a, g, lane, false, true, false, poll);
-            if (need_c && bad_c) scan_issue(a, g, lane, false, false, true, poll);
+            // (by every lane: a load under a per-lane condition into registers holding the other lanes' earlier values is a
+            // pattern one ROCm 7.2 build of the decoder's scan got wrong -- wah_decode.hip, sums_resolve)
+            scan_issue(a, g, lane, need_a, need_b, need_c, poll);
 #ifdef WAH_DIAG
             ++*dg_polls;
 #endif

@@ -270,9 +270,10 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
             if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
             break;
         }
-        if (need_a && bad_a != 0u) sum_scan_issue(block, row - row0, idx, n_slots, lane, true, false, false, poll);
-        if (need_b && bad_b != 0u) sum_scan_issue(block, row - row0, idx, n_slots, lane, false, true, false, poll);
-        if (need_c && bad_c) sum_scan_issue(block, row - row0, idx, n_slots, lane, false, false, true, poll);
+        // EVERY lane reads again, not only those whose entries were missing: a buffer load issued under a per-lane condition
+        // into registers that hold the other lanes' earlier values lost those values in one build of this very function
+        // (ROCm 7.2, inlined into the one-pass decoder of tools/experiments: bases made of the re-read lanes only)
+        sum_scan_issue(block, row - row0, idx, n_slots, lane, need_a, need_b, need_c, poll);
     }
     const u64 base = sat_add(sat_add(sum_c, sum_b), sum_a);
     const u64 end = sat_add(base, total);
