@@ -17,6 +17,7 @@
 //   * output offsets come from a one-hop "row scan" over 4-byte {epoch, count} granules written and read with
 //     agent-scope accesses (correct across the 8 non-coherent XCD L2s), instead of thrust::exclusive_scan + moveData
 //     (compress.cu:133-166, kernels.cu:273-280); nothing is persistent and nothing is cleared between launches.
+#include <cstdio>
 #include <cstdlib>
 
 #include "wah_device.hpp"
@@ -1439,6 +1440,16 @@ TileShape compress_tile_shape(uint64_t n_segments) {
     const uint64_t w = (uint64_t)kTileWaves;
     TileShape t = {3, 3, 0, 0};
     if (forced == 0) return TileShape{0, 0, 0, 0};
+    static const char *shape_env = std::getenv("WAH_SHAPE"); // experiments only: "big_tiles,tail_pairs" (body tiles of 3 pairs)
+    if (shape_env) {
+        unsigned long big = 0, tail = 0;
+        if (std::sscanf(shape_env, "%lu,%lu", &big, &tail) == 2 && tail >= 1 && tail <= 2 && big * w * 3 <= pairs) {
+            t.tail_pairs = (uint32_t)tail;
+            t.big_tiles = (uint32_t)big;
+            t.n_tiles = t.big_tiles + (uint32_t)((pairs - big * w * 3 + w * tail - 1) / (w * tail));
+            return t;
+        }
+    }
     if (forced >= 1 && forced <= 3) {
         t.body_pairs = t.tail_pairs = (uint32_t)forced;
         t.big_tiles = t.n_tiles = (uint32_t)((pairs + w * forced - 1) / (w * forced));
