@@ -1,7 +1,7 @@
 """AND of two 1 GiB bitmaps held compressed in HBM: wah_bitop_device (decode, decode, combine + compress) against
 wah_bitop_indexed_device (one combining pass through the segment indexes + compress)."""
 import importlib, os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 wah = importlib.import_module("gpu-wah_amd")
 lib = wah.lib()
 n = 268435200
