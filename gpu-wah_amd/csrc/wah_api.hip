@@ -457,10 +457,23 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
             a.n_tiles = shape.n_tiles;
         }
     }
-    if (unsegmented) { // fills cross the segment cut (compress_unseg_kernel): its own scan area, at most 4 segments per wave
+    if (unsegmented) { // fills cross the segment cut: its own scan area
         a.unseg_desc = reinterpret_cast<uint32_t *>(ws + l.unseg_off);
-        if (a.wave_segs > (uint32_t)wah::kCompressUnsegMaxWaveSegs) a.wave_segs = wah::kCompressUnsegMaxWaveSegs;
-        a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
+        static const bool old_body = [] { // experiments only: WAH_UNSEG_TILE_BODY=1 = the round-2 tile body (compress_unseg_kernel)
+            const char *f = std::getenv("WAH_UNSEG_TILE_BODY");
+            return f && f[0] == '1';
+        }();
+        const wah::TileShape shape = wah::compress_tile_shape(l.n_segments);
+        if (!no_wait && !old_body && shape.body_pairs) { // compress_unseg_pair_kernel: the pair-layout body and its tile shapes
+            a.pair_layout = 1;
+            a.wave_segs = 2 * shape.body_pairs;
+            a.tail_pairs = shape.tail_pairs;
+            a.big_tiles = shape.big_tiles;
+            a.n_tiles = shape.n_tiles;
+        } else { // compress_unseg_kernel: at most 4 segments per wave
+            if (a.wave_segs > (uint32_t)wah::kCompressUnsegMaxWaveSegs) a.wave_segs = wah::kCompressUnsegMaxWaveSegs;
+            a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
+        }
     }
     if (indexed) { // groups come from two indexed streams (bitop_tile_kernel): its own tile shape
         a.wave_segs = wah::kIndexedSegsPerWave;

@@ -848,6 +848,156 @@ __device__ __forceinline__ bool fold_right(const bool (&valid)[4], const bool (&
     return false;
 }
 
+// Wave 0 of a tile of the unsegmented mode (compress_unseg_body, compress_unseg_pair_body), after the tile's granule
+// {words, (T, L)} has gone out: the tile's offset and the length of the run that is open where it begins (the sweep of the
+// other tiles' granules is issued only here, late: compress_pair_body), the carries of the tile's waves (s_carry), what a
+// row's or superrow's last tile publishes, and what the launch's last tile leaves behind.
+__device__ __forceinline__ void unseg_tile_resolve(const CompressArgs &a, const ScanGeom &g, u32 *block, u64 *my_row, const LaunchEpoch &le, u32 tile,
+                                                   u32 total, u32 tile_t, u32 tile_l, u32 lane, const u32 *s_t, const u32 *s_l, u32 *s_carry,
+                                                   u64 *s_base) {
+    const u32 epoch = le.epoch;
+    UnsegSweep poll = {};
+    unseg_issue(block, g.row - g.row0, g.idx, g.n_slots, lane, true, g.has_prev, true, poll);
+    bool need_a = true, need_b = g.has_prev, need_c = true;
+    u64 words_a = 0, words_b = 0, words_c = 0, len_a = 0, len_b = 0, len_c = 0;
+    bool all_a = true, all_b = true;
+    u32 spins = 0;
+    auto granule = [](const u32x4 &q, int h) { return ((u64)(h ? q.w : q.y) << 32) | (h ? q.z : q.x); };
+    u64 *const slots_a = reinterpret_cast<u64 *>(block + kUnsegSlotsAAt);
+    u64 *const slots_b = reinterpret_cast<u64 *>(block + kUnsegSlotsBAt);
+    for (;;) {
+        u64 ba = 0, bb = 0, bc = 0;
+        u32 bad_a = 0, bad_b = 0;
+        bool bad_ca = false, bad_cb = false;
+        if (need_a) {
+            bool valid[4], t[4];
+            u64 len[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u64 gk = granule(poll.a[k >> 1], k & 1);
+                valid[k] = 4u * lane + k < g.idx;
+                if (valid[k] && (u32)(gk >> 48) != epoch) bad_a |= 1u << k;
+                t[k] = (gk & kUnsegT) != 0;
+                len[k] = gk & kUnsegLMask;
+                sum += (gk >> 32) & 0xFFFFull; // entries at and above my index lie behind the descriptor and read as zero
+            }
+            ba = __ballot(bad_a != 0u);
+            if (ba == 0) {
+                words_a = uniform64(wave_sum(sum));
+                all_a = fold_right(valid, t, len, lane, len_a);
+                need_a = false;
+                if (g.idx == kRowTiles - 1u && lane == 0) { // my row is complete with me: its words and its (T, L)
+                    __hip_atomic_store(slots_a + 1u + (g.row - g.row0), ((u64)epoch << 48) | (words_a + total), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    const u64 row_tl = tile_t ? ((all_a ? kSlotT : 0ull) | (len_a + tile_l)) : (u64)tile_l;
+                    __hip_atomic_store(slots_b + 1u + (g.row - g.row0), ((u64)epoch << 48) | row_tl, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (need_b) {
+            bool valid[4], t[4];
+            u64 len[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u64 gk = granule(poll.b[k >> 1], k & 1);
+                valid[k] = true;
+                if ((u32)(gk >> 48) != epoch) bad_b |= 1u << k;
+                t[k] = (gk & kUnsegT) != 0;
+                len[k] = gk & kUnsegLMask;
+                sum += (gk >> 32) & 0xFFFFull;
+            }
+            bb = __ballot(bad_b != 0u);
+            if (bb == 0) {
+                words_b = uniform64(wave_sum(sum));
+                all_b = fold_right(valid, t, len, lane, len_b);
+                need_b = false;
+            }
+        }
+        if (need_c) {
+            // slots 0 of superrow 0 are never written: nothing lies in front of the first tile
+            const bool wanted = lane < g.n_slots && !(g.sup == 0u && lane == 0u);
+            bad_ca = wanted && (u32)(poll.ca >> 48) != epoch;
+            bad_cb = wanted && (u32)(poll.cb >> 48) != epoch;
+            bc = __ballot(bad_ca || bad_cb);
+            if (bc == 0) {
+                words_c = uniform64(wave_sum(wanted ? poll.ca & ((1ull << 48) - 1ull) : 0ull));
+                // walk from the right: lane 0 (the superrow prefix, an absolute length) ends it at the latest
+                const bool stop = lane < g.n_slots && (lane == 0u || !(poll.cb & kSlotT));
+                const u32 hl = 63u - (u32)__builtin_clzll(__ballot(stop));
+                len_c = uniform64(wave_sum(wanted && lane >= hl ? poll.cb & kSlotLMask : 0ull));
+                need_c = false;
+            }
+        }
+        if (!(need_a || need_b || need_c)) break;
+        if (++spins > kMaxSpins) {
+            if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
+            break;
+        }
+        if ((u32)__builtin_popcountll(ba) + (u32)__builtin_popcountll(bb) + (u32)__builtin_popcountll(bc) <= kDirectLanes) {
+            // a few stragglers among the nearest predecessors (the usual case): read again at once, without parking on one word
+            __builtin_amdgcn_s_sleep(4);
+            unseg_issue(block, g.row - g.row0, g.idx, g.n_slots, lane, need_a, need_b, need_c, poll);
+            continue;
+        }
+        // wait for the missing entry with the highest tile number, then read what is missing again
+        const u64 *target;
+        if (need_a) {
+            const u32 hl = 63u - (u32)__builtin_clzll(ba);
+            const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_a, (int)hl);
+            target = my_row + 4u * hl + (31u - (u32)__builtin_clz(km));
+        } else if (need_b) {
+            const u32 hl = 63u - (u32)__builtin_clzll(bb);
+            const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_b, (int)hl);
+            target = my_row - kRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
+        } else {
+            const u32 hl = 63u - (u32)__builtin_clzll(bc);
+            target = (uniform32(__shfl((u32)bad_ca, (int)hl)) ? slots_a : slots_b) + hl;
+        }
+        bool timed_out = false;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((u32)(__hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 48) == epoch) break;
+            if (++spins > kMaxSpins) {
+                timed_out = true;
+                break;
+            }
+        }
+        if (timed_out) {
+            if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
+            break;
+        }
+        unseg_issue(block, g.row - g.row0, g.idx, g.n_slots, lane, need_a, need_b, need_c, poll);
+    }
+    const u64 base = words_c + words_b + words_a;
+    const u64 end = base + total;
+    // the run that is open in front of this tile: through my row, the previous one, the older rows, the prefix
+    u64 carry = len_a;
+    if (all_a) carry += g.has_prev ? (all_b ? len_b + len_c : len_b) : len_c;
+    u64 c = carry;
+    for (u32 w = 0; w < kTileWaves; ++w) {
+        if (lane == 0) s_carry[w] = (u32)c;
+        c = uniform32(s_t[w]) ? c + uniform32(s_l[w]) : (u64)uniform32(s_l[w]);
+    }
+    if (lane == 0) {
+        *s_base = base;
+        if (g.idx == kRowTiles - 1u && g.row - g.row0 == kSuperRows - 1u) { // last tile of a superrow: the next one's prefix
+            u32 *const nb = a.unseg_desc + (u64)(g.sup + 1u) * kUnsegBlockWords;
+            __hip_atomic_store(reinterpret_cast<u64 *>(nb + kUnsegSlotsAAt), ((u64)epoch << 48) | end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<u64 *>(nb + kUnsegSlotsBAt), ((u64)epoch << 48) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tile == a.n_tiles - 1) {
+            *a.out_words = end;
+            if (end > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+            if (a.host_result) {
+                a.host_result[1] = end;
+                a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
+            }
+            launch_epoch_end(a.ctrl, le);
+        }
+    }
+}
+
 // kMode: kTileScan = the one launch described above; kTileCount / kTilePlace = the two halves of its NO-WAIT route
 // (tile = blockIdx, nobody waits): count leaves {words, (T, L)} of every tile in a table, unseg_offsets_kernel turns them
 // into {first word, length of the run that is open where the tile begins}, place does the tile again and writes.
@@ -952,7 +1102,6 @@ __device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
     const ScanGeom g = scan_geom(tile);
     u32 *const block = a.unseg_desc + (u64)g.sup * kUnsegBlockWords;
     u64 *const my_row = reinterpret_cast<u64 *>(block) + (u64)(g.row - g.row0) * kRowTiles;
-    UnsegSweep poll = {};
     u32 total = 0, tile_t = 1u, tile_l = 0u;
     if (wave == 0) {
         const u32 mine = lane < kTileWaves ? s_count[lane] : 0u;
@@ -1000,142 +1149,8 @@ __device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
         }
         if (lane == 0) s_base = a.tile_counts[2ull * tile];
     }
-    if (kMode == kTileScan && wave == 0) {
-        // ---- the tile's offset and the run that is open where it begins (the sweep goes out only now: compress_pair_body) ---
-        unseg_issue(block, g.row - g.row0, g.idx, g.n_slots, lane, true, g.has_prev, true, poll);
-        bool need_a = true, need_b = g.has_prev, need_c = true;
-        u64 words_a = 0, words_b = 0, words_c = 0, len_a = 0, len_b = 0, len_c = 0;
-        bool all_a = true, all_b = true;
-        u32 spins = 0;
-        auto granule = [](const u32x4 &q, int h) { return ((u64)(h ? q.w : q.y) << 32) | (h ? q.z : q.x); };
-        u64 *const slots_a = reinterpret_cast<u64 *>(block + kUnsegSlotsAAt);
-        u64 *const slots_b = reinterpret_cast<u64 *>(block + kUnsegSlotsBAt);
-        for (;;) {
-            u64 ba = 0, bb = 0, bc = 0;
-            u32 bad_a = 0, bad_b = 0;
-            bool bad_ca = false, bad_cb = false;
-            if (need_a) {
-                bool valid[4], t[4];
-                u64 len[4], sum = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const u64 gk = granule(poll.a[k >> 1], k & 1);
-                    valid[k] = 4u * lane + k < g.idx;
-                    if (valid[k] && (u32)(gk >> 48) != epoch) bad_a |= 1u << k;
-                    t[k] = (gk & kUnsegT) != 0;
-                    len[k] = gk & kUnsegLMask;
-                    sum += (gk >> 32) & 0xFFFFull; // entries at and above my index lie behind the descriptor and read as zero
-                }
-                ba = __ballot(bad_a != 0u);
-                if (ba == 0) {
-                    words_a = uniform64(wave_sum(sum));
-                    all_a = fold_right(valid, t, len, lane, len_a);
-                    need_a = false;
-                    if (g.idx == kRowTiles - 1u && lane == 0) { // my row is complete with me: its words and its (T, L)
-                        __hip_atomic_store(slots_a + 1u + (g.row - g.row0), ((u64)epoch << 48) | (words_a + total), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                        const u64 row_tl = tile_t ? ((all_a ? kSlotT : 0ull) | (len_a + tile_l)) : (u64)tile_l;
-                        __hip_atomic_store(slots_b + 1u + (g.row - g.row0), ((u64)epoch << 48) | row_tl, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
-            }
-            if (need_b) {
-                bool valid[4], t[4];
-                u64 len[4], sum = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const u64 gk = granule(poll.b[k >> 1], k & 1);
-                    valid[k] = true;
-                    if ((u32)(gk >> 48) != epoch) bad_b |= 1u << k;
-                    t[k] = (gk & kUnsegT) != 0;
-                    len[k] = gk & kUnsegLMask;
-                    sum += (gk >> 32) & 0xFFFFull;
-                }
-                bb = __ballot(bad_b != 0u);
-                if (bb == 0) {
-                    words_b = uniform64(wave_sum(sum));
-                    all_b = fold_right(valid, t, len, lane, len_b);
-                    need_b = false;
-                }
-            }
-            if (need_c) {
-                // slots 0 of superrow 0 are never written: nothing lies in front of the first tile
-                const bool wanted = lane < g.n_slots && !(g.sup == 0u && lane == 0u);
-                bad_ca = wanted && (u32)(poll.ca >> 48) != epoch;
-                bad_cb = wanted && (u32)(poll.cb >> 48) != epoch;
-                bc = __ballot(bad_ca || bad_cb);
-                if (bc == 0) {
-                    words_c = uniform64(wave_sum(wanted ? poll.ca & ((1ull << 48) - 1ull) : 0ull));
-                    // walk from the right: lane 0 (the superrow prefix, an absolute length) ends it at the latest
-                    const bool stop = lane < g.n_slots && (lane == 0u || !(poll.cb & kSlotT));
-                    const u32 hl = 63u - (u32)__builtin_clzll(__ballot(stop));
-                    len_c = uniform64(wave_sum(wanted && lane >= hl ? poll.cb & kSlotLMask : 0ull));
-                    need_c = false;
-                }
-            }
-            if (!(need_a || need_b || need_c)) break;
-            if (++spins > kMaxSpins) {
-                if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
-                break;
-            }
-            // wait for the missing entry with the highest tile number, then read what is missing again
-            const u64 *target;
-            if (need_a) {
-                const u32 hl = 63u - (u32)__builtin_clzll(ba);
-                const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_a, (int)hl);
-                target = my_row + 4u * hl + (31u - (u32)__builtin_clz(km));
-            } else if (need_b) {
-                const u32 hl = 63u - (u32)__builtin_clzll(bb);
-                const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_b, (int)hl);
-                target = my_row - kRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
-            } else {
-                const u32 hl = 63u - (u32)__builtin_clzll(bc);
-                target = (uniform32(__shfl((u32)bad_ca, (int)hl)) ? slots_a : slots_b) + hl;
-            }
-            bool timed_out = false;
-            for (;;) {
-                __builtin_amdgcn_s_sleep(8);
-                if ((u32)(__hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 48) == epoch) break;
-                if (++spins > kMaxSpins) {
-                    timed_out = true;
-                    break;
-                }
-            }
-            if (timed_out) {
-                if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
-                break;
-            }
-            unseg_issue(block, g.row - g.row0, g.idx, g.n_slots, lane, need_a, need_b, need_c, poll);
-        }
-        const u64 base = words_c + words_b + words_a;
-        const u64 end = base + total;
-        // the run that is open in front of this tile: through my row, the previous one, the older rows, the prefix
-        u64 carry = len_a;
-        if (all_a) carry += g.has_prev ? (all_b ? len_b + len_c : len_b) : len_c;
-        u64 c = carry;
-        for (u32 w = 0; w < kTileWaves; ++w) {
-            if (lane == 0) s_carry[w] = (u32)c;
-            c = uniform32(s_t[w]) ? c + uniform32(s_l[w]) : (u64)uniform32(s_l[w]);
-        }
-        if (lane == 0) {
-            s_base = base;
-            if (g.idx == kRowTiles - 1u && g.row - g.row0 == kSuperRows - 1u) { // last tile of a superrow: the next one's prefix
-                u32 *const nb = a.unseg_desc + (u64)(g.sup + 1u) * kUnsegBlockWords;
-                __hip_atomic_store(reinterpret_cast<u64 *>(nb + kUnsegSlotsAAt), ((u64)epoch << 48) | end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(reinterpret_cast<u64 *>(nb + kUnsegSlotsBAt), ((u64)epoch << 48) | c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (tile == a.n_tiles - 1) {
-                *a.out_words = end;
-                if (end > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
-                if (a.host_result) {
-                    a.host_result[1] = end;
-                    a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
-                }
-                launch_epoch_end(a.ctrl, le);
-            }
-        }
-    }
+    if (kMode == kTileScan && wave == 0)
+        unseg_tile_resolve(a, g, block, my_row, le, tile, total, tile_t, tile_l, lane, s_t, s_l, s_carry, &s_base);
     __syncthreads();
 
     // ---- the parked words to their place: a continuing leading fill gets the open run's length, a continuing trailing
@@ -1216,6 +1231,8 @@ __global__ __launch_bounds__(64) void unseg_offsets_kernel(const CompressArgs a)
         }
     }
 }
+
+#include "wah_compress_unseg_pair.inc"
 
 template <bool kPair, bool kAligned, u32 kWaveSegs>
 __global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 2 ? 6 : 4) void compress_tile_kernel(const CompressArgs a) {
@@ -1313,6 +1330,20 @@ static void launch_tiles(const CompressArgs &a, hipStream_t s) {
 template <bool kAligned>
 static void launch_unseg(const CompressArgs &a, hipStream_t s) {
     const dim3 grid(a.n_tiles), block(kTileWaves * 64);
+    if (a.pair_layout) { // the pair-layout body (compress_unseg_pair_kernel): tile shapes as compress_pair_kernel's
+        const u32 body = a.wave_segs / 2, tail = a.tail_pairs;
+        if (body == 3 && tail == 1)
+            hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 3, 1>), grid, block, 0, s, a);
+        else if (body == 3 && tail == 2)
+            hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 3, 2>), grid, block, 0, s, a);
+        else if (body == 3)
+            hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 3, 3>), grid, block, 0, s, a);
+        else if (body == 2)
+            hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 2, 2>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 1, 1>), grid, block, 0, s, a);
+        return;
+    }
     switch (a.wave_segs) {
     case 1: hipLaunchKernelGGL((compress_unseg_kernel<kAligned, 1>), grid, block, 0, s, a); break;
     case 2: hipLaunchKernelGGL((compress_unseg_kernel<kAligned, 2>), grid, block, 0, s, a); break;
@@ -1371,7 +1402,7 @@ static void launch_pairs(const CompressArgs &a, hipStream_t s) {
 }
 
 hipError_t launch_compress(const CompressArgs &a, hipStream_t s) {
-    if (a.pair_layout) {
+    if (a.pair_layout && !a.unseg_desc) {
         if (a.fast_segments)
             launch_pairs<true>(a, s);
         else

@@ -407,6 +407,10 @@ def test_unsegmented_encoder_mode(wah, oracle):
              oracle.gen_clustered(992 * 600 + 11, 3, 50000), oracle.gen_uniform(992 * 40, 4, 0.3), alternating,
              islands(992 * 30000, 9, 1), islands(992 * 30000 + 77, 40, 2), islands(992 * 9000, 3, 3), np.zeros(31, np.uint32),
              oracle.gen_clustered(992 * 30000, 5, 2_000_000)]
+    for k in (2, 3, 24, 48, 50):  # runs of k whole segments, zeros and ones in turn: run ends ON pair, wave and tile boundaries
+        blocks = np.zeros((130, k, 992), np.uint32)
+        blocks[1::2] = 0xFFFFFFFF
+        cases.append(blocks.reshape(-1)[: 992 * (130 * k) - (5 if k == 3 else 0)].copy())
     for x in cases:
         comp = wah.DeviceCompressor(len(x), unsegmented=True)
         comp.run(_dev(x))
