@@ -457,23 +457,15 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
             a.n_tiles = shape.n_tiles;
         }
     }
-    if (unsegmented) { // fills cross the segment cut: its own scan area
+    if (unsegmented) { // fills cross the segment cut (compress_unseg_pair_kernel): its own scan area, the tile shapes of the plain compress
         a.unseg_desc = reinterpret_cast<uint32_t *>(ws + l.unseg_off);
-        static const bool old_body = [] { // experiments only: WAH_UNSEG_TILE_BODY=1 = the round-2 tile body (compress_unseg_kernel)
-            const char *f = std::getenv("WAH_UNSEG_TILE_BODY");
-            return f && f[0] == '1';
-        }();
         const wah::TileShape shape = wah::compress_tile_shape(l.n_segments);
-        if (!no_wait && !old_body && shape.body_pairs) { // compress_unseg_pair_kernel: the pair-layout body and its tile shapes
-            a.pair_layout = 1;
-            a.wave_segs = 2 * shape.body_pairs;
-            a.tail_pairs = shape.tail_pairs;
-            a.big_tiles = shape.big_tiles;
-            a.n_tiles = shape.n_tiles;
-        } else { // compress_unseg_kernel: at most 4 segments per wave
-            if (a.wave_segs > (uint32_t)wah::kCompressUnsegMaxWaveSegs) a.wave_segs = wah::kCompressUnsegMaxWaveSegs;
-            a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
-        }
+        const uint32_t body = shape.body_pairs ? shape.body_pairs : 3u; // (WAH_WAVE_PAIRS=0 switches only the plain compress's kernel off)
+        a.pair_layout = 1;
+        a.wave_segs = 2 * body;
+        a.tail_pairs = shape.body_pairs ? shape.tail_pairs : 3u;
+        a.big_tiles = shape.body_pairs ? shape.big_tiles : (uint32_t)ceil_div((l.n_segments + 1) / 2, (uint64_t)wah::kCompressTileWaves * 3u);
+        a.n_tiles = shape.body_pairs ? shape.n_tiles : a.big_tiles;
     }
     if (indexed) { // groups come from two indexed streams (bitop_tile_kernel): its own tile shape
         a.wave_segs = wah::kIndexedSegsPerWave;
@@ -481,7 +473,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
     }
     if (no_wait) { // count / scan / place: nobody waits for anybody.  Its own tile shape (two segments per wave; the plain
                    // compress: two pairs); the table of tile counts lies in the workspace's second half
-        a.wave_segs = (d_in2 || indexed || unsegmented) ? 2u : wah::compress_nowait_wave_segs();
+        a.wave_segs = (d_in2 || indexed) ? 2u : wah::compress_nowait_wave_segs(); // (plain and unsegmented: two PAIRS per wave)
         a.n_tiles = (uint32_t)ceil_div(l.n_segments, (uint64_t)wah::kCompressTileWaves * a.wave_segs);
         a.tile_counts = reinterpret_cast<uint64_t *>(ws + l.unseg_off);
         a.pair_layout = 0;

@@ -769,6 +769,8 @@ __device__ __forceinline__ void compress_tile_body(const CompressArgs &a, Source
     }
 }
 
+constexpr u32 kNoWaitWaveSegs = 4; // segments per wave of the no-wait routes on the pair body (two pairs)
+
 #include "wah_compress_pair.inc"
 
 // ===========================================================================
@@ -792,7 +794,7 @@ constexpr u64 kUnsegT = 1ull << 31;                 // granule: the tile is one 
 constexpr u64 kUnsegLMask = (1ull << 17) - 1ull;    // granule: length of the tile's trailing run
 constexpr u64 kSlotT = 1ull << 47;                  // slot B: the row is transparent
 constexpr u64 kSlotLMask = (1ull << 47) - 1ull;
-static_assert(kTileWaves * kCompressMaxWaveSegs * kSegGroups <= kUnsegLMask, "a tile's groups must fit the granule's L");
+static_assert(kTileWaves * 3u * 2u * kSegGroups <= kUnsegLMask, "a tile's groups (three pairs per wave) must fit the granule's L");
 static_assert(kUnsegBlockWords >= kUnsegSlotsBAt + 2 * kRowSlots && kUnsegSlotsAAt == 2 * kSuperRows * kRowTiles, "unsegmented scan block layout");
 
 __device__ __forceinline__ bool is_fill_group(u32 v) { return v == 0u || v == kOnes31; }
@@ -998,190 +1000,6 @@ __device__ __forceinline__ void unseg_tile_resolve(const CompressArgs &a, const 
     }
 }
 
-// kMode: kTileScan = the one launch described above; kTileCount / kTilePlace = the two halves of its NO-WAIT route
-// (tile = blockIdx, nobody waits): count leaves {words, (T, L)} of every tile in a table, unseg_offsets_kernel turns them
-// into {first word, length of the run that is open where the tile begins}, place does the tile again and writes.
-template <bool kAligned, u32 kWaveSegs, int kMode = kTileScan>
-__device__ __forceinline__ void compress_unseg_body(const CompressArgs &a) {
-    __shared__ __attribute__((aligned(16))) u32 s_out[kTileWaves][kOutWords];
-    __shared__ __attribute__((aligned(16))) unsigned short s_pos[kTileWaves][kPosEntries];
-    __shared__ u32 s_count[kTileWaves];
-    __shared__ u32 s_prefix[kTileWaves];
-    __shared__ u32 s_t[kTileWaves], s_l[kTileWaves]; // per wave: its segments are one continuing run / length of its trailing run
-    __shared__ u32 s_carry[kTileWaves];              // per wave: length of the run that is open where its first segment begins
-    __shared__ u64 s_base;
-    __shared__ u32 s_tile;
-
-    const u32 lane = lane_id();
-    const u32 wave = wave_id();
-    const u32 tile = kMode == kTileScan ? draw_tile(a.ctrl, &s_tile) : blockIdx.x;
-    const u32 seg0 = (tile * kTileWaves + wave) * kWaveSegs;
-    LaunchEpoch le = {};
-    if (kMode == kTileScan) {
-        le = launch_epoch_begin(a.ctrl, tile, a.n_tiles, a.gen_desc, a.scan_words, a.keep_error);
-        if (le.bad) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) *a.out_words = 0;
-            return;
-        }
-    } else if (kMode == kTileCount && tile == 0 && threadIdx.x == 0 && !a.keep_error) {
-        __hip_atomic_store(a.ctrl + kCtlError, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const u32 epoch = le.epoch;
-
-    u32 *const stage = s_out[wave];
-    unsigned short *const pos = s_pos[wave];
-    u32 out[kWaveSegs][16];
-    u32 cnt[kWaveSegs], nval[kWaveSegs], first[kWaveSegs], last[kWaveSegs], tail[kWaveSegs];
-    bool single[kWaveSegs], merge[kWaveSegs], drop[kWaveSegs];
-    SegGroups grp[kWaveSegs];
-    SegEnds ends[kWaveSegs];
-    u32 never;
-    asm volatile("v_mov_b32 %0, -1" : "=v"(never));
-    BitmapSource<false, kAligned> src;
-    src.begin(a, seg0, kWaveSegs, lane);
-    // the group in front of the wave's first segment and the one behind its last: one word of the bitmap each
-    const u32 seg_next = seg0 + kWaveSegs;
-    u32 prev_last = 1u, next_first = 1u; // 1: not a fill group
-    if (seg0 > 0 && seg0 < a.n_segments) prev_last = a.in[(u64)seg0 * kSegWords - 1u] >> 1;
-    if (seg_next < a.n_segments) next_first = ((u64)seg_next * kSegWords < a.n_words ? a.in[(u64)seg_next * kSegWords] : 0u) & kOnes31;
-
-    // ---- pass 1 of all the wave's segments, and what each of them has at its two ends -----------------------------------
-#pragma unroll
-    for (u32 j = 0; j < kWaveSegs; ++j) {
-        const u32 seg = seg0 + j;
-        cnt[j] = 0;
-        nval[j] = kSegGroups;
-        first[j] = last[j] = 1u;
-        tail[j] = 0;
-        single[j] = false;
-        if (seg < a.n_segments) {
-            nval[j] = (seg == a.n_segments - 1) ? a.last_segment_groups : kSegGroups;
-            src.produce(a, seg, j + 1 < kWaveSegs, nval[j], stage, pos, lane, grp[j]);
-            const u32 raw = classify_pass1(grp[j], never, ends[j]);
-            cnt[j] = raw - (kSegGroups - nval[j]);
-            first[j] = uniform32(grp[j].x[0]);
-            if (nval[j] == kSegGroups) {
-                last[j] = (u32)__builtin_amdgcn_readlane((int)grp[j].x[kSteps - 1], 63);
-                single[j] = raw == 1u;
-                // length of the trailing run = distance from the last run end in front of group 1023 (flag word: bit 15 - s
-                // = group 64 s + lane ends a run; group 1023 always does)
-                const u32 fm = ends[j] & ~(lane == 63u ? 1u : 0u);
-                const u32 p1 = fm ? 64u * (15u - (u32)__builtin_ctz(fm)) + lane + 1u : 0u; // 1 + position of my last run end
-                const u32 mx = (u32)__builtin_amdgcn_readlane((int)wave_scan_max32(p1), 63);
-                tail[j] = is_fill_group(last[j]) ? kSegGroups - mx : 0u;
-            }
-        }
-    }
-    u32 count = 0, wave_t = 1u, wave_l = 0u;
-#pragma unroll
-    for (u32 j = 0; j < kWaveSegs; ++j) {
-        const u32 seg = seg0 + j;
-        merge[j] = drop[j] = false;
-        if (seg < a.n_segments) {
-            const u32 before = j ? last[j - 1] : prev_last;
-            merge[j] = seg > 0 && is_fill_group(before) && first[j] == before && (seg & (kCutSegs - 1u)) != 0u;
-            const u32 after = j + 1 < kWaveSegs ? first[j + 1] : next_first;
-            drop[j] = seg + 1 < a.n_segments && is_fill_group(last[j]) && after == last[j] && ((seg + 1u) & (kCutSegs - 1u)) != 0u;
-            count += cnt[j] - (drop[j] ? 1u : 0u);
-            if (single[j] && merge[j]) {
-                wave_l += kSegGroups;
-            } else {
-                wave_t = 0u;
-                wave_l = tail[j];
-            }
-        }
-    }
-    if (lane == 0) {
-        s_count[wave] = count;
-        s_t[wave] = wave_t;
-        s_l[wave] = wave_l;
-    }
-    __syncthreads();
-
-    // ---- wave 0: count and (T, L) of the tile go out in one granule, the sweep is issued ---------------------------------
-    const ScanGeom g = scan_geom(tile);
-    u32 *const block = a.unseg_desc + (u64)g.sup * kUnsegBlockWords;
-    u64 *const my_row = reinterpret_cast<u64 *>(block) + (u64)(g.row - g.row0) * kRowTiles;
-    u32 total = 0, tile_t = 1u, tile_l = 0u;
-    if (wave == 0) {
-        const u32 mine = lane < kTileWaves ? s_count[lane] : 0u;
-        const u32 incl = wave_scan_incl32(mine);
-        if (lane < kTileWaves) s_prefix[lane] = incl - mine;
-        total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        for (u32 w = 0; w < kTileWaves; ++w) {
-            if (uniform32(s_t[w])) {
-                tile_l += uniform32(s_l[w]);
-            } else {
-                tile_t = 0u;
-                tile_l = uniform32(s_l[w]);
-            }
-        }
-        if (kMode == kTileCount) {
-            if (lane == 0) {
-                a.tile_counts[2ull * tile] = total;
-                a.tile_counts[2ull * tile + 1] = (tile_t ? kSlotT : 0ull) | tile_l;
-            }
-        } else if (kMode == kTileScan && lane == 0) {
-            __hip_atomic_store(my_row + g.idx, ((u64)epoch << 48) | ((u64)total << 32) | (tile_t ? kUnsegT : 0ull) | tile_l, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (kMode == kTileCount) return;
-
-    // ---- pass 2 of all segments: compaction in LDS, final words into registers -----------------------------------------
-#pragma unroll
-    for (u32 j = 0; j < kWaveSegs; ++j) {
-        if (seg0 + j < a.n_segments) {
-            if (lane == 0) pos[0] = 0xFFFFu;
-            classify_pass2(grp[j], ends[j], stage, pos, lane, cnt[j] < kSparseBelow);
-            const bool any_fill = segment_has_fill(grp[j], cnt[j] + (kSegGroups - nval[j]), nval[j]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            final_words_to_regs(stage, pos, lane, cnt[j], any_fill, out[j]);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
-    }
-
-    if (kMode == kTilePlace && wave == 0) { // both out of the table (unseg_offsets_kernel)
-        u64 c = a.tile_counts[2ull * tile + 1];
-        for (u32 w = 0; w < kTileWaves; ++w) {
-            if (lane == 0) s_carry[w] = (u32)c;
-            c = uniform32(s_t[w]) ? c + uniform32(s_l[w]) : (u64)uniform32(s_l[w]);
-        }
-        if (lane == 0) s_base = a.tile_counts[2ull * tile];
-    }
-    if (kMode == kTileScan && wave == 0)
-        unseg_tile_resolve(a, g, block, my_row, le, tile, total, tile_t, tile_l, lane, s_t, s_l, s_carry, &s_base);
-    __syncthreads();
-
-    // ---- the parked words to their place: a continuing leading fill gets the open run's length, a continuing trailing
-    //      fill is left to the segment in which the run ends ------------------------------------------------------------------
-    u64 base = uniform64(s_base) + uniform32(s_prefix[wave]);
-    u32 c = uniform32(s_carry[wave]);
-#pragma unroll
-    for (u32 j = 0; j < kWaveSegs; ++j) {
-        if (seg0 + j < a.n_segments) {
-            const u32 ci = merge[j] ? c : 0u;
-            if (lane == 0) out[j][0] += ci; // (count of the leading fill; ci = 0 otherwise)
-            const u32 n_out = cnt[j] - (drop[j] ? 1u : 0u);
-            emit_regs(a, base, n_out, lane, out[j]);
-            base += n_out;
-            c = single[j] && merge[j] ? ci + kSegGroups : tail[j];
-        }
-    }
-}
-
-// (two segments per wave need 90 registers: held to the 80 of six waves per SIMD the kernel spilled 18 of them)
-template <bool kAligned, u32 kWaveSegs>
-__global__ __launch_bounds__(kTileWaves * 64, kWaveSegs <= 1 ? 6 : 4) void compress_unseg_kernel(const CompressArgs a) {
-    compress_unseg_body<kAligned, kWaveSegs>(a);
-}
-
-// ---- the no-wait route of the unsegmented mode: two segments per wave, whatever the size of the bitmap --------------
-template <bool kAligned, int kMode>
-__global__ __launch_bounds__(kTileWaves * 64, 4) void compress_unseg_nowait_kernel(const CompressArgs a) {
-    compress_unseg_body<kAligned, 2, kMode>(a);
-}
-
 // {words, (T, L)} of every tile -> {first word, length of the run that is open where the tile begins}, in place; + what
 // the last tile of the scan route leaves behind.  ONE wavefront: the (T, L) of consecutive tiles fold like
 //   (T1, L1) . (T2, L2) = (T1 & T2, T2 ? L1 + L2 : L2)
@@ -1248,7 +1066,6 @@ __global__ __launch_bounds__(kTileWaves * 64, 4) void compress_tile_pair_nowait_
 }
 
 // ---- the no-wait route (kTileCount / kTilePlace of compress_pair_body): two pairs per wave, whatever the size of the bitmap ------
-constexpr u32 kNoWaitWaveSegs = 4;
 template <bool kAligned, int kMode>
 __global__ __launch_bounds__(kTileWaves * 64, 4) void compress_nowait_kernel(const CompressArgs a) {
     __shared__ __attribute__((aligned(1024))) u32 s_stage[kTileWaves][kPairStageWords]; // (the swizzle is made of address bits 7-9)
@@ -1328,27 +1145,19 @@ static void launch_tiles(const CompressArgs &a, hipStream_t s) {
 }
 
 template <bool kAligned>
-static void launch_unseg(const CompressArgs &a, hipStream_t s) {
+static void launch_unseg(const CompressArgs &a, hipStream_t s) { // compress_unseg_pair_kernel: tile shapes as compress_pair_kernel's
     const dim3 grid(a.n_tiles), block(kTileWaves * 64);
-    if (a.pair_layout) { // the pair-layout body (compress_unseg_pair_kernel): tile shapes as compress_pair_kernel's
-        const u32 body = a.wave_segs / 2, tail = a.tail_pairs;
-        if (body == 3 && tail == 1)
-            hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 3, 1>), grid, block, 0, s, a);
-        else if (body == 3 && tail == 2)
-            hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 3, 2>), grid, block, 0, s, a);
-        else if (body == 3)
-            hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 3, 3>), grid, block, 0, s, a);
-        else if (body == 2)
-            hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 2, 2>), grid, block, 0, s, a);
-        else
-            hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 1, 1>), grid, block, 0, s, a);
-        return;
-    }
-    switch (a.wave_segs) {
-    case 1: hipLaunchKernelGGL((compress_unseg_kernel<kAligned, 1>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((compress_unseg_kernel<kAligned, 2>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((compress_unseg_kernel<kAligned, 4>), grid, block, 0, s, a); break;
-    }
+    const u32 body = a.wave_segs / 2, tail = a.tail_pairs;
+    if (body == 3 && tail == 1)
+        hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 3, 1>), grid, block, 0, s, a);
+    else if (body == 3 && tail == 2)
+        hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 3, 2>), grid, block, 0, s, a);
+    else if (body == 3)
+        hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 3, 3>), grid, block, 0, s, a);
+    else if (body == 2)
+        hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 2, 2>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((compress_unseg_pair_kernel<kAligned, 1, 1>), grid, block, 0, s, a);
 }
 
 uint32_t compress_nowait_wave_segs() { return kNoWaitWaveSegs; }
@@ -1363,13 +1172,13 @@ hipError_t launch_compress_nowait(const CompressArgs &a, hipStream_t s) {
     }
     if (a.unseg_desc) { // unsegmented mode
         if (a.fast_segments) {
-            hipLaunchKernelGGL((compress_unseg_nowait_kernel<true, kTileCount>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((compress_unseg_pair_nowait_kernel<true, kTileCount>), grid, block, 0, s, a);
             hipLaunchKernelGGL(unseg_offsets_kernel, dim3(1), dim3(64), 0, s, a);
-            hipLaunchKernelGGL((compress_unseg_nowait_kernel<true, kTilePlace>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((compress_unseg_pair_nowait_kernel<true, kTilePlace>), grid, block, 0, s, a);
         } else {
-            hipLaunchKernelGGL((compress_unseg_nowait_kernel<false, kTileCount>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((compress_unseg_pair_nowait_kernel<false, kTileCount>), grid, block, 0, s, a);
             hipLaunchKernelGGL(unseg_offsets_kernel, dim3(1), dim3(64), 0, s, a);
-            hipLaunchKernelGGL((compress_unseg_nowait_kernel<false, kTilePlace>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((compress_unseg_pair_nowait_kernel<false, kTilePlace>), grid, block, 0, s, a);
         }
         return hipGetLastError();
     }

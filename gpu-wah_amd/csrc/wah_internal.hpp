@@ -57,11 +57,10 @@ constexpr uint32_t kRowSlots = 65;                 // u64 slots of a superrow: w
 constexpr uint32_t kScanSlotsAt = 64 * 256;        // 32-bit words: the slots follow the superrow's granules
 constexpr uint32_t kScanBlockWords = 64 * 256 + 256; // granules + slots, padded to 1 KiB
 constexpr uint64_t kScanBlockTiles = 64 * 256;
-// ... and of its unsegmented mode (compress_unseg_kernel): 8-byte granules, two slot arrays
+// ... and of its unsegmented mode (compress_unseg_pair_kernel): 8-byte granules, two slot arrays
 constexpr uint32_t kUnsegSlotsAAt = 2 * 64 * 256;          // 32-bit words
 constexpr uint32_t kUnsegSlotsBAt = 2 * 64 * 256 + 256;
 constexpr uint32_t kUnsegBlockWords = 2 * 64 * 256 + 512;
-constexpr int kCompressUnsegMaxWaveSegs = 4; // (registers: first / last / tail / flags per segment on top of the groups)
 
 // ---- decode geometry -------------------------------------------------------
 constexpr int kScanTileWords = 4096; // compressed words per tile (both decode passes)
@@ -93,7 +92,7 @@ struct CompressArgs {
     uint64_t *seg_offsets; // optional, n_segments + 1 entries
     uint32_t *ctrl;        // kCtlWords
     uint32_t *gen_desc;    // scan area: blocks of kScanBlockWords (see compress_tile_kernel)
-    uint32_t *unseg_desc;  // non-null: unsegmented mode, its scan area: blocks of kUnsegBlockWords (compress_unseg_kernel)
+    uint32_t *unseg_desc;  // non-null: unsegmented mode, its scan area: blocks of kUnsegBlockWords (compress_unseg_pair_kernel)
     uint64_t *tile_counts; // no-wait route only: one entry per tile, its word count, then where its words start
     uint64_t scan_words;   // 32-bit words of the whole scan area
     int keep_error;        // 1: the control block was cleared by the caller and may already hold an upstream error
