@@ -778,10 +778,11 @@ constexpr u32 kNoWaitWaveSegs = 4; // segments per wave of the no-wait routes on
 // the stream that wah_merge_fills_device makes of compress()'s -- a fill may cross the 1024-group cut of
 // kernels.cu:68,188-229 (but not a multiple of 2^29 groups, so that every count fits 30 bits).
 //
-// Where the cut falls inside a run, segment s + 1 begins with the same fill group segment s ends with: a LOCAL property
-// of two groups.  The run's word is written by the segment in which the run ENDS; every earlier piece is dropped:
-//   drop_s   = the trailing fill of segment s continues into s + 1        -> segment s emits one word less (its last)
-//   merge_s  = the leading fill of segment s continues one from s - 1     -> its first word's count grows by carry_s
+// The unit is the PAIR of segments a wavefront classifies at once (compress_unseg_pair_body, wah_compress_unseg_pair.inc).
+// Where the pairs' cut falls inside a run, pair s + 1 begins with the same fill group pair s ends with: a LOCAL property
+// of two groups.  The run's word is written by the pair in which the run ENDS; every earlier piece is dropped:
+//   drop_s   = the trailing fill of pair s continues into s + 1           -> pair s emits one word less (its last)
+//   merge_s  = the leading fill of pair s continues one from s - 1        -> its first word's count grows by carry_s
 // so the word counts stay ADDITIVE (count_s - drop_s) and the offsets come from the same row scan.  What crosses tiles
 // is the length of the run that is open at a tile's end -- and it only passes THROUGH tiles that are one single run
 // ("transparent", T): a tile publishes (T, L) beside its count, L = length of its trailing run (if T: its group count),
@@ -850,7 +851,7 @@ __device__ __forceinline__ bool fold_right(const bool (&valid)[4], const bool (&
     return false;
 }
 
-// Wave 0 of a tile of the unsegmented mode (compress_unseg_body, compress_unseg_pair_body), after the tile's granule
+// Wave 0 of a tile of the unsegmented mode (compress_unseg_pair_body), after the tile's granule
 // {words, (T, L)} has gone out: the tile's offset and the length of the run that is open where it begins (the sweep of the
 // other tiles' granules is issued only here, late: compress_pair_body), the carries of the tile's waves (s_carry), what a
 // row's or superrow's last tile publishes, and what the launch's last tile leaves behind.
