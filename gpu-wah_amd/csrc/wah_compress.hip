@@ -851,6 +851,31 @@ __device__ __forceinline__ bool fold_right(const bool (&valid)[4], const bool (&
     return false;
 }
 
+// (T, L) of the tile's waves folded by the lanes of wave 0 (lane w = wave w; lanes behind the last wave: transparent,
+// length 0) instead of one wave after the other -- sixteen dependent LDS reads on the way to the tile's publication, and
+// sixteen more in front of its second barrier.
+//   unseg_fold_tile:    the tile's own (T, L)
+//   unseg_wave_carries: lane w <- length of the run that is open where wave w begins, given the one open where the tile
+//                       begins (c_in); returns the one open where the tile ends
+__device__ __forceinline__ void unseg_fold_tile(const u32 *s_t, const u32 *s_l, u32 lane, u32 &tile_t, u32 &tile_l) {
+    const u32 t = lane < kTileWaves ? s_t[lane] : 1u, l = lane < kTileWaves ? s_l[lane] : 0u;
+    const u64 non_t = __ballot(t == 0u);
+    tile_t = non_t == 0 ? 1u : 0u;
+    const u32 from = non_t == 0 ? 0u : 63u - (u32)__builtin_clzll(non_t); // the last wave that is not transparent
+    tile_l = uniform32(wave_sum32(lane >= from ? l : 0u));
+}
+__device__ __forceinline__ u64 unseg_wave_carries(const u32 *s_t, const u32 *s_l, u32 *s_carry, u64 c_in, u32 lane) {
+    const u32 t = lane < kTileWaves ? s_t[lane] : 1u, l = lane < kTileWaves ? s_l[lane] : 0u;
+    const u64 non_t = __ballot(t == 0u);
+    const u32 excl = wave_scan_incl32(l) - l;             // lengths of the waves below me
+    const u64 below = non_t & ((1ull << lane) - 1ull);    // waves below me that are not transparent
+    const u32 v = below ? 63u - (u32)__builtin_clzll(below) : 0u;
+    const u32 excl_v = (u32)__shfl((int)excl, (int)v);
+    const u64 c = below ? (u64)(excl - excl_v) : c_in + excl;
+    if (lane < kTileWaves) s_carry[lane] = (u32)c;
+    return uniform64(__shfl(c, (int)kTileWaves));         // ("wave 8": behind the tile's last wave)
+}
+
 // Wave 0 of a tile of the unsegmented mode (compress_unseg_pair_body), after the tile's granule
 // {words, (T, L)} has gone out: the tile's offset and the length of the run that is open where it begins (the sweep of the
 // other tiles' granules is issued only here, late: compress_pair_body), the carries of the tile's waves (s_carry), what a
@@ -977,11 +1002,7 @@ __device__ __forceinline__ void unseg_tile_resolve(const CompressArgs &a, const 
     // the run that is open in front of this tile: through my row, the previous one, the older rows, the prefix
     u64 carry = len_a;
     if (all_a) carry += g.has_prev ? (all_b ? len_b + len_c : len_b) : len_c;
-    u64 c = carry;
-    for (u32 w = 0; w < kTileWaves; ++w) {
-        if (lane == 0) s_carry[w] = (u32)c;
-        c = uniform32(s_t[w]) ? c + uniform32(s_l[w]) : (u64)uniform32(s_l[w]);
-    }
+    const u64 c = unseg_wave_carries(s_t, s_l, s_carry, carry, lane);
     if (lane == 0) {
         *s_base = base;
         if (g.idx == kRowTiles - 1u && g.row - g.row0 == kSuperRows - 1u) { // last tile of a superrow: the next one's prefix
