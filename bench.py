@@ -490,6 +490,11 @@ def run_rank(args):
         algo_d = 4.0 * c_words + 4.0 * ((31 * groups + 31) // 32)  # decompress: read C, write N'
         achieved = algo_c / (comp_avg * 1e-3) / 1e9
         achieved_d = algo_d / (dec_avg * 1e-3) / 1e9
+        # the general decoder's route (wah_api.hip: decode_common): one pass over the stream when the output is at most eight
+        # times the stream, sums + expand for highly compressed streams (few tiles that expand a lot each)
+        one_pass = (n + 1) // 8 <= c_words and os.environ.get("WAH_DECODE_TWO_PASS") != "1" and os.environ.get("WAH_FORCE_FALLBACK") != "1"
+        decode_kernels = ("decode_tile_kernel (+ decode_expand_list_kernel: the tiles it defers, normally none)" if one_pass
+                          else "decode_sums_kernel + decode_expand_kernel")
         tr = load_traffic(args.workload) or {}
         out = {
             "metric": "compress+decompress GB/s (input bits), 1 GiB bitmap",
@@ -514,7 +519,7 @@ def run_rank(args):
                          "launch_ms_isolated": round(comp_isolated, 4),
                          "frac_isolated": round(algo_c / (comp_isolated * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                          "frac_of_copy_ceiling": round(achieved / copy_gbps, 4)},
-            "roofline_decompress": {"kernel": "decode_sums_kernel + decode_expand_kernel", "bound": "hbm",
+            "roofline_decompress": {"kernel": decode_kernels, "bound": "hbm",
                                     "achieved": round(achieved_d, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": round(achieved_d / HBM_PEAK_GBPS, 4),
                                     "traffic": tr.get("decompress_bytes_per_launch"), "traffic_measured_in_run": False,

@@ -76,19 +76,21 @@ CompressLayout compress_layout(uint64_t n_words, size_t workspace_bytes = 0) {
 
 struct DecodeLayout {
     uint64_t n_tiles;
-    size_t ctrl_off, desc_off, base_off, flags_off, half, total, scan_bytes;
+    size_t ctrl_off, desc_off, base_off, flags_off, defer_off, half, total, scan_bytes;
 };
 
-// first half: scan area of the sums kernel (one block per 64 x 256 workgroup tiles, + the one a full last superrow
-// publishes into); second half: tile bases, then one flag byte per tile (rewritten by every call, no epochs)
+// first half: scan area of the sums kernel / of the one-pass decoder (one block per 64 x 256 workgroup tiles, + the one a full
+// last superrow publishes into; the one-pass decoder's workgroup tiles are the shorter ones: 8192 words); second half: tile
+// bases, one flag byte per tile, the one-pass decoder's list of deferred tiles (rewritten by every call, no epochs)
 DecodeLayout decode_layout(uint64_t c_words, size_t workspace_bytes = 0) {
     DecodeLayout l;
     l.n_tiles = ceil_div(c_words, (uint64_t)wah::kScanTileWords);
-    const uint64_t wg_tiles = ceil_div(l.n_tiles, (uint64_t)wah::kSumTilesPerGroup);
+    const uint64_t wg_tiles = ceil_div(c_words, (uint64_t)wah::kDecodeTileWords);
     const uint64_t blocks = wg_tiles / wah::kSumScanBlockTiles + 1;
     const size_t scan_need = blocks * wah::kSumScanBlockWords * sizeof(uint32_t);
     const size_t base_bytes = round256((l.n_tiles + 4) * sizeof(uint64_t)); // (+ two words for wah_validate_device)
-    const size_t rest_need = base_bytes + round256(l.n_tiles + 16);           // one byte per tile: contains empty fills
+    const size_t flag_bytes = round256(l.n_tiles + 16);                       // one byte per tile: contains empty fills
+    const size_t rest_need = base_bytes + flag_bytes + round256((l.n_tiles + 2 + 64) * sizeof(uint32_t)); // + deferred tiles
     const size_t need_half = round256(scan_need > rest_need ? scan_need : rest_need);
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
@@ -98,6 +100,7 @@ DecodeLayout decode_layout(uint64_t c_words, size_t workspace_bytes = 0) {
     l.scan_bytes = l.half; // (the wrap-around clear covers the whole first half, whatever was launched into it)
     l.base_off = l.desc_off + l.half;
     l.flags_off = l.base_off + base_bytes;
+    l.defer_off = l.flags_off + flag_bytes; // the list (its counters: kCtlDefer in the control block)
     if (l.half < need_half) l.total = w + 1;
     return l;
 }
@@ -590,6 +593,53 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
     hipStream_t s = static_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(d_workspace);
     hipError_t e = hipSuccess;
+    // ONE pass over the stream (decode_tile_kernel) when the scan and the expansion are asked for together, the stream is
+    // 16-byte aligned and the output is at most eight times the stream (a highly compressed stream has few tiles that expand
+    // a lot each: decode_expand_kernel shares such a tile out over many workgroups, and its second read of the stream costs
+    // next to nothing).  WAH_DECODE_TWO_PASS=1: never (experiments, tests of the two-pass route).
+    static const bool two_pass_only = [] {
+        const char *f = std::getenv("WAH_DECODE_TWO_PASS");
+        return f && f[0] == '1';
+    }();
+    const bool one_pass = do_scan && do_expand && !no_wait && !two_pass_only && c_words != 0 && aligned16(d_comp) &&
+                          out_capacity_words / 8 <= c_words;
+    if (one_pass) {
+        if (clear_first) e = wah::launch_clear(ws, l.base_off, s); // (control block -- with the deferred tiles' counters -- and scan area)
+        if (e != hipSuccess) {
+            set_err("clearing the workspace", e);
+            return WAH_ERR_HIP;
+        }
+        wah::ScanArgs a;
+        a.comp = d_comp;
+        a.c_words = c_words;
+        a.n_tiles = l.n_tiles;
+        a.info = d_out_info;
+        a.tile_base = reinterpret_cast<uint64_t *>(ws + l.base_off);
+        a.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
+        a.gen_desc = reinterpret_cast<uint32_t *>(ws + l.desc_off);
+        a.scan_words = l.scan_bytes / sizeof(uint32_t);
+        a.tile_flags = reinterpret_cast<uint8_t *>(ws + l.flags_off);
+        a.aligned16 = 1;
+        a.host_result = host_result;
+        a.no_wait = 0;
+        wah::ExpandArgs x;
+        x.comp = d_comp;
+        x.c_words = c_words;
+        x.out = d_out;
+        x.out_capacity = out_capacity_words;
+        x.info = d_out_info;
+        x.tile_base = a.tile_base;
+        x.tile_flags = a.tile_flags;
+        x.ctrl = a.ctrl;
+        x.aligned16 = 1;
+        x.parts = 1;
+        e = wah::launch_decode_tiles(a, x, reinterpret_cast<uint32_t *>(ws + l.defer_off), s);
+        if (e != hipSuccess) {
+            set_err("decode tile kernel launch", e);
+            return WAH_ERR_HIP;
+        }
+        return WAH_OK;
+    }
     if (do_scan) {
         if (clear_first) e = wah::launch_clear(ws, l.base_off, s);
         if (e == hipSuccess && c_words == 0) {

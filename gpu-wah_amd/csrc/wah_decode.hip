@@ -53,8 +53,15 @@ struct SumScan {
     u64 c;            // slot of my superrow: lane 0 = groups in front of it, lane 1 + k = groups of its row k
 };
 
-__device__ __forceinline__ void sum_scan_issue(u32 *block, u32 row_in_super, u32 idx, u32 n_slots, u32 lane, bool need_a, bool need_b,
+// The descriptors are made of values that ARE the same in every lane (the tile's number and what follows from it); they
+// are passed through readfirstlane all the same: where the compiler cannot prove it (seen in decode_tile_kernel, where the
+// call sits inside `if (wave == 0)` of a large unrolled body) it wraps every load in a "waterfall" loop over the distinct
+// descriptors, and a re-read issued for SOME lanes then came back with the other lanes' earlier values zeroed (ROCm 7.2;
+// tools/dbg_decode_tile.py: the base of a first-generation tile of row 2 = the entries of lanes 30..61 only).
+__device__ __forceinline__ void sum_scan_issue(u32 *block_, u32 row_in_super_, u32 idx_, u32 n_slots_, u32 lane, bool need_a, bool need_b,
                                                bool need_c, SumScan &p) {
+    u32 *const block = reinterpret_cast<u32 *>(uniform64(reinterpret_cast<u64>(block_)));
+    const u32 row_in_super = uniform32(row_in_super_), idx = uniform32(idx_), n_slots = uniform32(n_slots_);
     if (need_a) {
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(block + (u64)row_in_super * kSumRowTiles * 2u, idx * 8u);
         p.a[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, lane * 32u, 0, kAuxSc1);
@@ -70,6 +77,122 @@ __device__ __forceinline__ void sum_scan_issue(u32 *block, u32 row_in_super, u32
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rc, lane * 8u, 0, kAuxSc1);
         p.c = ((u64)v.y << 32) | v.x;
     }
+}
+
+// Wave 0 of a workgroup tile of a scan kernel (decode_sums_kernel, decode_tile_kernel), once the tile's total is known:
+// publishes it as ONE 8-byte granule {epoch:16, groups:48} and resolves the groups in front of the tile with the one-hop
+// ROW SCAN described at decode_sums_kernel; the last tile of a row publishes the row's slot, the last tile of a superrow
+// the next superrow's slot[0].  Returns the groups in front of the tile; `end` = that + total, both saturating at 2^47
+// (overflow: reported by the caller as WAH_ERR_STREAM).  kPublish = false: the caller has published the granule already
+// (sums_publish) and sweeps LATE -- the sweep of a tile that has other work to do first is the cheaper the later it goes out,
+// as in compress_pair_kernel.
+__device__ __forceinline__ void sums_publish(u32 *gen_desc, u32 wt, u32 epoch, u64 total) {
+    const u32 row = wt / kSumRowTiles, idx = wt % kSumRowTiles, sup = row / kSumSuperRows, row0 = sup * kSumSuperRows;
+    u64 *const my_row = reinterpret_cast<u64 *>(gen_desc + (u64)sup * kSumScanBlockWords) + (u64)(row - row0) * kSumRowTiles;
+    __hip_atomic_store(my_row + idx, ((u64)epoch << kSumSlotShift) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool kPublish = true>
+__device__ __forceinline__ u64 sums_resolve(u32 *ctrl, u32 *gen_desc, u32 wt, u32 epoch, u64 total, u32 lane, u64 &end) {
+    const u32 row = wt / kSumRowTiles, idx = wt % kSumRowTiles, sup = row / kSumSuperRows, row0 = sup * kSumSuperRows;
+    const bool has_prev = row > row0;
+    const u32 n_slots = has_prev ? row - row0 : 1u;
+    u32 *const block = gen_desc + (u64)sup * kSumScanBlockWords;
+    u64 *const my_row = reinterpret_cast<u64 *>(block) + (u64)(row - row0) * kSumRowTiles;
+    u64 *const slots = reinterpret_cast<u64 *>(block + kSumScanSlotsAt);
+    if (kPublish && lane == 0) __hip_atomic_store(my_row + idx, ((u64)epoch << kSumSlotShift) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    SumScan poll = {};
+    bool need_a = true, need_b = has_prev, need_c = true;
+    sum_scan_issue(block, row - row0, idx, n_slots, lane, need_a, need_b, need_c, poll);
+    u64 sum_a = 0, sum_b = 0, sum_c = 0;
+    u32 spins = 0;
+    auto granule = [](const u32x4 &q, int h) { return ((u64)(h ? q.w : q.y) << 32) | (h ? q.z : q.x); };
+    for (;;) {
+        u32 bad_a = 0, bad_b = 0;
+        bool bad_c = false;
+        u64 ba = 0, bb = 0, bc = 0;
+        if (need_a) {
+            u64 sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u64 gk = granule(poll.a[k >> 1], k & 1);
+                if (4u * lane + k < idx && (u32)(gk >> kSumSlotShift) != epoch) bad_a |= 1u << k;
+                sum += gk & kSumValueMask; // entries at and above my index lie behind the descriptor and read as zero
+            }
+            ba = __ballot(bad_a != 0u);
+            if (ba == 0) {
+                sum_a = uniform64(wave_sum(sum));
+                need_a = false;
+                if (idx == kSumRowTiles - 1u && lane == 0) // my row is complete with me: publish its total
+                    __hip_atomic_store(slots + 1u + (row - row0), ((u64)epoch << kSumSlotShift) | sat_add(sum_a, total), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (need_b) {
+            u64 sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u64 gk = granule(poll.b[k >> 1], k & 1);
+                if ((u32)(gk >> kSumSlotShift) != epoch) bad_b |= 1u << k;
+                sum += gk & kSumValueMask;
+            }
+            bb = __ballot(bad_b != 0u);
+            if (bb == 0) {
+                sum_b = uniform64(wave_sum(sum));
+                need_b = false;
+            }
+        }
+        if (need_c) {
+            // slot 0 of superrow 0 is never written: nothing lies in front of the first tile
+            const bool wanted = lane < n_slots && !(sup == 0u && lane == 0u);
+            bad_c = wanted && (u32)(poll.c >> kSumSlotShift) != epoch;
+            bc = __ballot(bad_c);
+            if (bc == 0) {
+                sum_c = uniform64(wave_sum(wanted ? poll.c & kSumValueMask : 0ull));
+                need_c = false;
+            }
+        }
+        if (!(need_a || need_b || need_c)) break;
+        if (++spins > kMaxSpins) {
+            if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
+            break;
+        }
+        // wait for the missing entry with the highest tile number (published last), then read the missing lanes again
+        const u64 *target;
+        if (need_a) {
+            const u32 hl = 63u - (u32)__builtin_clzll(ba);
+            const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_a, (int)hl);
+            target = my_row + 4u * hl + (31u - (u32)__builtin_clz(km));
+        } else if (need_b) {
+            const u32 hl = 63u - (u32)__builtin_clzll(bb);
+            const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_b, (int)hl);
+            target = my_row - kSumRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
+        } else {
+            target = slots + (63u - (u32)__builtin_clzll(bc));
+        }
+        bool timed_out = false;
+        for (;;) {
+            __builtin_amdgcn_s_sleep(8);
+            if ((u32)(__hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> kSumSlotShift) == epoch) break;
+            if (++spins > kMaxSpins) {
+                timed_out = true;
+                break;
+            }
+        }
+        if (timed_out) {
+            if (lane == 0) atomicOr(ctrl + kCtlError, kErrTimeout);
+            break;
+        }
+        // every lane reads again, not only those whose entries were missing: a re-read under a per-lane condition came back
+        // with the OTHER lanes' earlier values gone in decode_tile_kernel (ROCm 7.2; tools/dbg_decode_tile.py)
+        sum_scan_issue(block, row - row0, idx, n_slots, lane, need_a, need_b, need_c, poll);
+    }
+    const u64 base = sat_add(sat_add(sum_c, sum_b), sum_a);
+    end = sat_add(base, total);
+    if (lane == 0 && idx == kSumRowTiles - 1u && row - row0 == kSumSuperRows - 1u) // last tile of a superrow
+        __hip_atomic_store(reinterpret_cast<u64 *>(gen_desc + (u64)(sup + 1u) * kSumScanBlockWords + kSumScanSlotsAt),
+                           ((u64)epoch << kSumSlotShift) | end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return base;
 }
 
 // kWaveTiles: expand tiles a wavefront sums one after the other (long streams: 4, so that ticket, barrier and scan are
@@ -180,111 +303,13 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
     u64 total = uniform64(__shfl(incl_part, 63));
     bool overflow = total >= kSumSaturate;
     if (overflow) total = kSumSaturate;
-    const u32 row = wt / kSumRowTiles, idx = wt % kSumRowTiles, sup = row / kSumSuperRows, row0 = sup * kSumSuperRows;
-    const bool has_prev = row > row0;
-    const u32 n_slots = has_prev ? row - row0 : 1u;
-    u32 *const block = a.gen_desc + (u64)sup * kSumScanBlockWords;
-    u64 *const my_row = reinterpret_cast<u64 *>(block) + (u64)(row - row0) * kSumRowTiles;
-    u64 *const slots = reinterpret_cast<u64 *>(block + kSumScanSlotsAt);
-    if (lane == 0) __hip_atomic_store(my_row + idx, ((u64)epoch << kSumSlotShift) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-    SumScan poll = {};
-    bool need_a = true, need_b = has_prev, need_c = true;
-    sum_scan_issue(block, row - row0, idx, n_slots, lane, need_a, need_b, need_c, poll);
-    u64 sum_a = 0, sum_b = 0, sum_c = 0;
-    u32 spins = 0;
-    auto granule = [](const u32x4 &q, int h) { return ((u64)(h ? q.w : q.y) << 32) | (h ? q.z : q.x); };
-    for (;;) {
-        u32 bad_a = 0, bad_b = 0;
-        bool bad_c = false;
-        u64 ba = 0, bb = 0, bc = 0;
-        if (need_a) {
-            u64 sum = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const u64 gk = granule(poll.a[k >> 1], k & 1);
-                if (4u * lane + k < idx && (u32)(gk >> kSumSlotShift) != epoch) bad_a |= 1u << k;
-                sum += gk & kSumValueMask; // entries at and above my index lie behind the descriptor and read as zero
-            }
-            ba = __ballot(bad_a != 0u);
-            if (ba == 0) {
-                sum_a = uniform64(wave_sum(sum));
-                need_a = false;
-                if (idx == kSumRowTiles - 1u && lane == 0) // my row is complete with me: publish its total
-                    __hip_atomic_store(slots + 1u + (row - row0), ((u64)epoch << kSumSlotShift) | sat_add(sum_a, total), __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        if (need_b) {
-            u64 sum = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const u64 gk = granule(poll.b[k >> 1], k & 1);
-                if ((u32)(gk >> kSumSlotShift) != epoch) bad_b |= 1u << k;
-                sum += gk & kSumValueMask;
-            }
-            bb = __ballot(bad_b != 0u);
-            if (bb == 0) {
-                sum_b = uniform64(wave_sum(sum));
-                need_b = false;
-            }
-        }
-        if (need_c) {
-            // slot 0 of superrow 0 is never written: nothing lies in front of the first tile
-            const bool wanted = lane < n_slots && !(sup == 0u && lane == 0u);
-            bad_c = wanted && (u32)(poll.c >> kSumSlotShift) != epoch;
-            bc = __ballot(bad_c);
-            if (bc == 0) {
-                sum_c = uniform64(wave_sum(wanted ? poll.c & kSumValueMask : 0ull));
-                need_c = false;
-            }
-        }
-        if (!(need_a || need_b || need_c)) break;
-        if (++spins > kMaxSpins) {
-            if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
-            break;
-        }
-        // wait for the missing entry with the highest tile number (published last), then read the missing lanes again
-        const u64 *target;
-        if (need_a) {
-            const u32 hl = 63u - (u32)__builtin_clzll(ba);
-            const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_a, (int)hl);
-            target = my_row + 4u * hl + (31u - (u32)__builtin_clz(km));
-        } else if (need_b) {
-            const u32 hl = 63u - (u32)__builtin_clzll(bb);
-            const u32 km = (u32)__builtin_amdgcn_readlane((int)bad_b, (int)hl);
-            target = my_row - kSumRowTiles + 4u * hl + (31u - (u32)__builtin_clz(km));
-        } else {
-            target = slots + (63u - (u32)__builtin_clzll(bc));
-        }
-        bool timed_out = false;
-        for (;;) {
-            __builtin_amdgcn_s_sleep(8);
-            if ((u32)(__hip_atomic_load(target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> kSumSlotShift) == epoch) break;
-            if (++spins > kMaxSpins) {
-                timed_out = true;
-                break;
-            }
-        }
-        if (timed_out) {
-            if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrTimeout);
-            break;
-        }
-        // EVERY lane reads again, not only those whose entries were missing: a buffer load issued under a per-lane condition
-        // into registers that hold the other lanes' earlier values lost those values in one build of this very function
-        // (ROCm 7.2, inlined into the one-pass decoder of tools/experiments: bases made of the re-read lanes only)
-        sum_scan_issue(block, row - row0, idx, n_slots, lane, need_a, need_b, need_c, poll);
-    }
-    const u64 base = sat_add(sat_add(sum_c, sum_b), sum_a);
-    const u64 end = sat_add(base, total);
+    u64 end;
+    const u64 base = sums_resolve(a.ctrl, a.gen_desc, wt, epoch, total, lane, end);
     overflow |= end >= kSumSaturate;
     // lane w: groups in front of expand tile et0 + w (wave 0: et0 = the workgroup tile's first expand tile)
     if (lane < kSumWaves * kWaveTiles && et0 + lane < n_tiles) a.tile_base[et0 + lane] = base + (incl_part - part);
     if (lane == 0) {
         if (overflow) atomicOr(a.ctrl + kCtlError, kErrStream);
-        if (idx == kSumRowTiles - 1u && row - row0 == kSumSuperRows - 1u) // last tile of a superrow
-            __hip_atomic_store(reinterpret_cast<u64 *>(a.gen_desc + (u64)(sup + 1u) * kSumScanBlockWords + kSumScanSlotsAt),
-                               ((u64)epoch << kSumSlotShift) | end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (wt == n_wg_tiles - 1) {
             a.tile_base[n_tiles] = end;
             a.info[1] = end;
@@ -582,21 +607,19 @@ __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, u32 *s_
     expand_emit(a, s_words, flag, tile_w0, first_word, nvalid, out_words, seg, wi <= kTileLdsWords, lane);
 }
 
-__global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const ExpandArgs a) {
+// one expand tile (4096 words of the stream): the output segments that start inside it (every parts-th batch of them).
+// (The LDS arrays are this function's own: decode_expand_kernel and decode_expand_list_kernel each inline it once.)
+__device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 part, u32 parts) {
     __shared__ __attribute__((aligned(16))) u32 s_words[kTileLdsWords];
     __shared__ u64 s_coarse[kCoarse + 1]; // groups in front of word 64 c, relative to the tile start
     __shared__ u32 s_coarse32[kCoarse + 1]; // the same in 32 bits (valid when the tile total is below 2^31)
     __shared__ u64 s_wave_sum[kExpandWaves];
     __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][kFlagBytes]; // 1: a word starts at this group
-
     const u32 lane = lane_id();
     const u32 wave = wave_id();
-    // a stream of few tiles (highly compressed data) expands to many segments per tile: `parts` workgroups share a tile
 #ifdef WAH_DIAG
     const u64 dg_start = __builtin_amdgcn_s_memrealtime();
 #endif
-    const u32 tile = blockIdx.x / a.parts;
-    const u32 part = blockIdx.x % a.parts;
     const u64 tile_w0 = (u64)tile * kScanTileWords;
     const u64 groups = a.info[1];
     const u64 out_words = a.info[0];
@@ -604,7 +627,7 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
     const u64 all_tiles = (a.c_words + kScanTileWords - 1) / kScanTileWords;
     const bool has_empties = (a.tile_flags[tile] | ((u64)tile + 1 < all_tiles ? a.tile_flags[tile + 1] : 0)) != 0;
     if (out_words > a.out_capacity) {
-        if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+        if (threadIdx.x == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
         return;
     }
 
@@ -667,14 +690,14 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
         // hold its 1024-entry index map
         static_assert(sizeof(s_flag) >= kSegGroups * sizeof(u32), "index map must fit the flag areas");
         if (wave == 0)
-            for (u64 seg = k_begin + part; seg < k_end; seg += a.parts)
+            for (u64 seg = k_begin + part; seg < k_end; seg += parts)
                 expand_segment_with_empties(a, s_words, s_coarse, reinterpret_cast<u32 *>(&s_flag[0][0]), tile_w0, base, groups,
                                             out_words, seg, lane);
         return;
     }
     unsigned char *flag = s_flag[wave];
     const bool tame = total < (1ull << 31); // wave-uniform: positions inside this tile fit 32 bits
-    for (u64 seg = k_begin + wave + (u64)kExpandWaves * part; seg < k_end; seg += (u64)kExpandWaves * a.parts) {
+    for (u64 seg = k_begin + wave + (u64)kExpandWaves * part; seg < k_end; seg += (u64)kExpandWaves * parts) {
         if (tame) {
             const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
             expand_segment_tame(a, s_words, s_coarse32, flag, tile_w0, (u32)(seg * kSegGroups - base), nvalid, out_words, seg, lane);
@@ -693,6 +716,34 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
     }
 #endif
 }
+
+// a stream of few tiles (highly compressed data) expands to many segments per tile: `parts` workgroups share a tile
+__global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const ExpandArgs a) {
+    expand_tile(a, blockIdx.x / a.parts, blockIdx.x % a.parts, a.parts);
+}
+
+// the expand tiles decode_tile_kernel left to this route (giant fills, fill words of count 0: foreign streams), out of its
+// list; normally the list is empty and the launch ends at once.  The last workgroup to finish empties the list.
+__global__ __launch_bounds__(kExpandThreads) void decode_expand_list_kernel(const ExpandArgs a, const u32 *list, u32 *count, u32 capacity) {
+    // a workspace that the first launch refused (WAH_ERR_WORKSPACE: neither zeroed nor left by a launch) holds no list
+    if (__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kErrWorkspace) return;
+    const u64 n_et = (a.c_words + kScanTileWords - 1) / kScanTileWords;
+    u32 n = uniform32(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (n > capacity) n = capacity; // (whatever the counter holds: every access stays inside the list and the stream)
+    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
+        const u32 tile = uniform32(list[i]);
+        if (tile < n_et) expand_tile(a, tile, 0, 1);
+        __syncthreads(); // the LDS image goes to the next tile
+    }
+    if (threadIdx.x == 0) { // count[1]: workgroups of this launch that are done
+        if (__hip_atomic_fetch_add(count + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
+            __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+#include "wah_decode_tile.inc"
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Decoding with the segment index (wah_decompress_segments_device).  A stream of compress() never lets a fill cross a
@@ -902,6 +953,38 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
     if (parts > 1024) parts = 1024;
     a.parts = (u32)parts;
     hipLaunchKernelGGL(decode_expand_kernel, dim3((unsigned)(n_tiles * parts)), dim3(kExpandThreads), 0, s, a);
+    return hipGetLastError();
+}
+
+// the general decoder in one pass (decode_tile_kernel) + the launch that takes what it deferred
+hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u32 *defer, hipStream_t s) {
+    static const u32 batch = [] { // tiles per workgroup: 2 (experiments: WAH_DT_BATCH=1)
+        const char *e = std::getenv("WAH_DT_BATCH");
+        return e && e[0] == '1' ? 1u : 2u;
+    }();
+    TileDecodeArgs t;
+    t.comp = sa.comp;
+    t.c_words = sa.c_words;
+    t.n_wg_tiles = (u32)((sa.c_words + (u64)batch * kDtTileWords - 1) / ((u64)batch * kDtTileWords));
+    t.out = xa.out;
+    t.out_capacity = xa.out_capacity;
+    t.info = sa.info;
+    t.tile_base = sa.tile_base;
+    t.tile_flags = sa.tile_flags;
+    t.defer_count = sa.ctrl + kCtlDefer; // [0] entries, [1] workgroups of the second launch that are done (wah_internal.hpp)
+    t.defer_list = defer;
+    t.defer_capacity = (u32)sa.n_tiles + 2u; // (decode_layout: room for n_tiles + 2 + 64 entries)
+    t.ctrl = sa.ctrl;
+    t.gen_desc = sa.gen_desc;
+    t.scan_words = sa.scan_words;
+    t.host_result = sa.host_result;
+    if (batch == 1)
+        hipLaunchKernelGGL(decode_tile_kernel<1>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t);
+    else
+        hipLaunchKernelGGL(decode_tile_kernel<2>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t);
+    ExpandArgs x = xa;
+    x.parts = 1;
+    hipLaunchKernelGGL(decode_expand_list_kernel, dim3(1024), dim3(kExpandThreads), 0, s, x, (const u32 *)t.defer_list, t.defer_count, t.defer_capacity);
     return hipGetLastError();
 }
 

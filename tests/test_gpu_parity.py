@@ -689,6 +689,30 @@ def test_workspace_serves_different_sizes_in_turn(wah, oracle):
         assert np.array_equal(_host(dec.result())[:n], data), n
 
 
+def test_decode_workspace_named_with_different_sizes(wah, oracle):
+    """One decode workspace BUFFER, handed over with the size each stream needs (what the host entry points do with the
+    buffer they keep): the areas behind the control block then lie elsewhere from call to call, and nothing in them may be
+    taken for an earlier call's state -- the one-pass decoder once kept the count of its deferred tiles there and walked a
+    list of an earlier call's tile bases."""
+    import torch
+
+    sizes = [992 * 40, 992 * 300 + 5, 992 * 40, 2_000_000, 992 * 40, 31, 992 * 300 + 5]
+    streams = [oracle.compress(oracle.gen_uniform(n, 40 + i, 0.5 if i % 2 == 0 else 0.02)) for i, n in enumerate(sizes)]
+    L = wah.lib()
+    ws_max = max(int(L.wah_decompress_workspace_bytes(len(st), 0)) for st in streams)
+    ws = torch.zeros(ws_max, dtype=torch.uint8, device="cuda")  # zeroed ONCE
+    out = torch.empty(max(sizes) + 2, dtype=torch.int32, device="cuda")
+    info = torch.zeros(2, dtype=torch.int64, device="cuda")
+    for rnd in range(2):
+        for n, st in zip(sizes, streams):
+            d = _dev(st)
+            ws_bytes = int(L.wah_decompress_workspace_bytes(len(st), 0))
+            rc = L.wah_decompress_device(d.data_ptr(), len(st), out.data_ptr(), n + 2, info.data_ptr(), ws.data_ptr(), ws_bytes, None)
+            assert rc == 0, (n, rc)
+            assert L.wah_decompress_status(ws.data_ptr(), None) == 0, n
+            assert np.array_equal(_host(out[:n]), oracle.decompress(st)[:n]), n
+
+
 _SCAN_ROUTE_ONLY = pytest.mark.skipif(os.environ.get("WAH_FORCE_FALLBACK") == "1",
                                       reason="tests the scan route's workspace protocol (epochs, tickets); WAH_FORCE_FALLBACK=1 "
                                              "sends every launch down the no-wait route, which reads nothing of the workspace")

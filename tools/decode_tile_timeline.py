@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Time line of decode_tile_kernel (DIAGNOSTIC build: the stamps overwrite the head of the output buffer): per tile, when it
+started, had its words staged, published its total, had its start flags, knew its base, finished (s_memrealtime, 100 MHz).
+usage: python tools/decode_tile_timeline.py [sparse|dense ...]"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["WAH_LIB_PATH"] = os.path.join(ROOT, "gpu-wah_amd", "libwah_hip_diag.so")
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+wah = importlib.import_module("gpu-wah_amd")
+n = 268435200
+for kind in sys.argv[1:] or ["sparse"]:
+    d = {"sparse": lambda: wah.gen_uniform_device(n, 1337, 0.01), "dense": lambda: wah.gen_uniform_device(n, 1337, 0.5)}[kind]()
+    comp = wah.DeviceCompressor(n)
+    comp.run(d)
+    stream = comp.result().clone()
+    del comp
+    dec = wah.DeviceDecompressor(stream.numel(), n + 1)
+    dec.run(stream)
+    dec.status()
+    dec.run(stream)
+    dec.status()
+    n_tiles = (stream.numel() + 8191) // 8192
+    t = dec.out[: n_tiles * 16].view(torch.int64).cpu().numpy().reshape(n_tiles, 8)
+    start, staged, pub, flags, base, bar3, end, segs = (t[:, i] for i in range(8))
+    t0 = start.min()
+    us = lambda x: x / 100.0
+    q = lambda x: f"{us(x.mean()):.2f} (p10 {us(np.percentile(x, 10)):.2f}, p90 {us(np.percentile(x, 90)):.2f})"
+    print(f"--- {kind}: {n_tiles} tiles of 8192 words, {segs.mean():.1f} segments per tile, span {us(end.max() - t0):.1f} us")
+    print(f"   start -> words staged            {q(staged - start)}")
+    print(f"   -> counted, barrier 1 (publish)  {q(pub - staged)}")
+    print(f"   -> start flags, barrier 2        {q(flags - pub)}")
+    print(f"   -> base known (wave 0)           {q(base - flags)}")
+    print(f"   -> barrier 3                     {q(bar3 - base)}")
+    print(f"   -> segments expanded, end        {q(end - bar3)}")
+    print(f"   tile life                        {q(end - start)}")
+    s = us(start - t0)
+    e = us(end - t0)
+    for x in np.arange(0, e.max() + 50, 50.0):
+        print(f"   {x:6.1f} us: in flight {int(np.sum((s <= x) & (x < e))):4d}  started {int(np.sum(s <= x)):6d}")
+    del dec, d, stream

@@ -59,7 +59,9 @@ for wl in ("sparse", "clustered", "dense"):
         return (2.0 * t.get("FETCH_SIZE", 0) + t.get("WRITE_SIZE", 0)) * 1024.0
     summary[wl] = {
         "compress_bytes_per_launch": hbm("compress_pair_kernel"),
-        "decompress_bytes_per_launch": hbm("decode_sums_kernel") + hbm("decode_expand_kernel"),
+        # the general decoder: one pass (decode_tile_kernel + the launch over its list of deferred tiles) or, for highly
+        # compressed streams, sums + expand -- whichever kernels ran
+        "decompress_bytes_per_launch": hbm("decode_tile_kernel") + hbm("decode_expand_list_kernel") + hbm("decode_sums_kernel") + hbm("decode_expand_kernel"),
         "decompress_indexed_bytes_per_launch": hbm("decode_segments_kernel"),
         "source": f"profiles/{os.path.basename(out).replace('profiles_', '')}_summary.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md",
         "raw_KiB": tr,
@@ -72,7 +74,7 @@ for wl in ("sparse", "clustered", "dense"):
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{out}/sq_p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(compress_pair_kernel|decode_sums_kernel|decode_expand_kernel)", r["Kernel_Name"])
+        m = re.search(r"(compress_pair_kernel|decode_tile_kernel|decode_sums_kernel|decode_expand_kernel)", r["Kernel_Name"])
         if m:
             agg[m.group(1)][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(f"{out}/pmc_sq_counters_sparse.txt", "w") as o:
@@ -98,9 +100,10 @@ with open(f"{out}/pmc_sq_counters_sparse.txt", "w") as o:
                     f"waiting (s_waitcnt / barrier) {mean('SQ_WAIT_ANY')/mean('SQ_WAVE_CYCLES'):.2f}\n")
         if c.get("SQ_LDS_IDX_ACTIVE"):
             o.write(f"  LDS bank conflict cycles / LDS active cycles: {mean('SQ_LDS_BANK_CONFLICT')/mean('SQ_LDS_IDX_ACTIVE'):.2f}\n")
-    e = agg.get("decode_expand_kernel", {})
-    if e.get("SQ_LDS_IDX_ACTIVE"):
-        o.write(f"== decode_expand_kernel: LDS bank conflict cycles / LDS active cycles: {sum(e['SQ_LDS_BANK_CONFLICT'])/len(e['SQ_LDS_BANK_CONFLICT'])/(sum(e['SQ_LDS_IDX_ACTIVE'])/len(e['SQ_LDS_IDX_ACTIVE'])):.2f}\n")
+    for dk in ("decode_tile_kernel", "decode_expand_kernel"):
+      e = agg.get(dk, {})
+      if e.get("SQ_LDS_IDX_ACTIVE"):
+        o.write(f"== {dk}: LDS bank conflict cycles / LDS active cycles: {sum(e['SQ_LDS_BANK_CONFLICT'])/len(e['SQ_LDS_BANK_CONFLICT'])/(sum(e['SQ_LDS_IDX_ACTIVE'])/len(e['SQ_LDS_IDX_ACTIVE'])):.2f}\n")
 print(open(f"{out}/pmc_sq_counters_sparse.txt").read())
 open(f"{out}/summary.txt", "w").write("\n".join(lines) + "\n")
 json.dump(summary, open(f"{out}/traffic.json", "w"), indent=1)
