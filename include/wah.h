@@ -152,11 +152,16 @@ int wah_compress_status(void *d_workspace, void *stream);
 
 /* d_comp: c_words compressed words, 16-byte aligned.  d_out: room for
  * out_capacity_words decoded words.  d_out_info: two device uint64:
- * [0] = ceil(31*G/32) decoded words, [1] = G groups. */
+ * [0] = ceil(31*G/32) decoded words, [1] = G groups.
+ * A stream whose output (out_capacity_words) is at most eight times its size is decoded in ONE pass over it; a more
+ * highly compressed one by a scan of the stream + an expansion pass (as _scan_device + _expand_device).  If the decoded
+ * words do not fit out_capacity_words: WAH_ERR_CAPACITY from wah_decompress_status(), and d_out holds at most the part
+ * that fits (the one-pass route writes as it goes, the other one nothing). */
 int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                           uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* The same with flags.  WAH_NO_WAIT: the sums pass by a route in which no workgroup waits for another -- every 4096-word
+/* The same with flags.  WAH_NO_WAIT: the scan of the stream by a route in which no workgroup waits for another (and the
+ * two-launch form of the decoder, whatever the stream) -- every 4096-word
  * tile's group total to a table, then one scan launch over the table (the reference's getCounts ->
  * thrust::exclusive_scan, decompress.cu:66-80, with one entry per tile instead of one per word); the expand pass never
  * waits anyway.  It is what decompress() takes by itself when a bounded wait of the one-launch sums kernel has expired

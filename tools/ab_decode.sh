@@ -1,6 +1,6 @@
-# A/B of the general decoder's routes on the 1 GiB bitmaps (tools/decode_ab.py): two launches, one pass with 1 / 2 / 3 tiles per workgroup
+# A/B of the general decoder's routes on the 1 GiB bitmaps (tools/decode_ab.py): two launches, one pass with 1 / 2 tiles per workgroup
 cd $GRAFT_REPO_ROOT
 WAH_DECODE_TWO_PASS=1 timeout -k 10 120 python tools/decode_ab.py sparse dense || exit 1
-for b in 1 2 3; do
+for b in 1 2; do
   WAH_DT_BATCH=$b timeout -k 10 120 python tools/decode_ab.py sparse dense || exit 1
 done
