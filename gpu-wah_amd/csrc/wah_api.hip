@@ -90,7 +90,7 @@ DecodeLayout decode_layout(uint64_t c_words, size_t workspace_bytes = 0) {
     const size_t scan_need = blocks * wah::kSumScanBlockWords * sizeof(uint32_t);
     const size_t base_bytes = round256((l.n_tiles + 4) * sizeof(uint64_t)); // (+ two words for wah_validate_device)
     const size_t flag_bytes = round256(l.n_tiles + 16);                       // one byte per tile: contains empty fills
-    const size_t rest_need = base_bytes + flag_bytes + round256((l.n_tiles + 2 + 64) * sizeof(uint32_t)); // + deferred tiles
+    const size_t rest_need = base_bytes + flag_bytes + round256((l.n_tiles + c_words / 3968 + 2 + 64) * sizeof(uint64_t)); // + deferred tiles (launch_decode_tiles)
     const size_t need_half = round256(scan_need > rest_need ? scan_need : rest_need);
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
@@ -633,7 +633,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         x.ctrl = a.ctrl;
         x.aligned16 = 1;
         x.parts = 1;
-        e = wah::launch_decode_tiles(a, x, reinterpret_cast<uint32_t *>(ws + l.defer_off), s);
+        e = wah::launch_decode_tiles(a, x, reinterpret_cast<uint64_t *>(ws + l.defer_off), s);
         if (e != hipSuccess) {
             set_err("decode tile kernel launch", e);
             return WAH_ERR_HIP;

@@ -723,23 +723,21 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
 }
 
 // the expand tiles decode_tile_kernel left to this route (giant fills, fill words of count 0: foreign streams), out of its
-// list; normally the list is empty and the launch ends at once.  The last workgroup to finish empties the list.
-__global__ __launch_bounds__(kExpandThreads) void decode_expand_list_kernel(const ExpandArgs a, const u32 *list, u32 *count, u32 capacity) {
+// list; normally the list is empty and the launch ends at once.
+__global__ __launch_bounds__(kExpandThreads) void decode_expand_list_kernel(const ExpandArgs a, const u64 *list, const u32 *count, u32 capacity) {
     // a workspace that the first launch refused (WAH_ERR_WORKSPACE: neither zeroed nor left by a launch) holds no list
     if (__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kErrWorkspace) return;
     const u64 n_et = (a.c_words + kScanTileWords - 1) / kScanTileWords;
-    u32 n = uniform32(__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    // the counter of the launch that has just ended (count[2] = launches so far; wah_internal.hpp, kCtlDefer): read only --
+    // the NEXT one-pass launch zeroes it
+    const u32 seq = uniform32(__hip_atomic_load(count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    u32 n = uniform32(__hip_atomic_load(count + ((seq - 1u) & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (n > capacity) n = capacity; // (whatever the counter holds: every access stays inside the list and the stream)
     for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
-        const u32 tile = uniform32(list[i]);
-        if (tile < n_et) expand_tile(a, tile, 0, 1);
+        const u64 e = uniform64(list[i]); // {tile:32, part:16, parts:16}: dt_defer
+        const u32 tile = (u32)e, part = (u32)(e >> 32) & 0xFFFFu, parts = (u32)(e >> 48);
+        if (tile < n_et && parts != 0u && part < parts) expand_tile(a, tile, part, parts);
         __syncthreads(); // the LDS image goes to the next tile
-    }
-    if (threadIdx.x == 0) { // count[1]: workgroups of this launch that are done
-        if (__hip_atomic_fetch_add(count + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) {
-            __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(count + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
     }
 }
 
@@ -957,7 +955,7 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
 }
 
 // the general decoder in one pass (decode_tile_kernel) + the launch that takes what it deferred
-hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u32 *defer, hipStream_t s) {
+hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *defer, hipStream_t s) {
     static const u32 batch = [] { // tiles per workgroup: 2 (experiments: WAH_DT_BATCH=1)
         const char *e = std::getenv("WAH_DT_BATCH");
         return e && e[0] == '1' ? 1u : 2u;
@@ -971,9 +969,9 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u32 *de
     t.info = sa.info;
     t.tile_base = sa.tile_base;
     t.tile_flags = sa.tile_flags;
-    t.defer_count = sa.ctrl + kCtlDefer; // [0] entries, [1] workgroups of the second launch that are done (wah_internal.hpp)
+    t.defer_count = sa.ctrl + kCtlDefer; // (wah_internal.hpp)
     t.defer_list = defer;
-    t.defer_capacity = (u32)sa.n_tiles + 2u; // (decode_layout: room for n_tiles + 2 + 64 entries)
+    t.defer_capacity = (u32)(sa.n_tiles + sa.c_words / 3968u + 2u); // (decode_layout; dt_defer: one entry per tile + one per 32 segments of output, and the output is at most 8 x the stream)
     t.ctrl = sa.ctrl;
     t.gen_desc = sa.gen_desc;
     t.scan_words = sa.scan_words;
@@ -984,7 +982,7 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u32 *de
         hipLaunchKernelGGL(decode_tile_kernel<2>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t);
     ExpandArgs x = xa;
     x.parts = 1;
-    hipLaunchKernelGGL(decode_expand_list_kernel, dim3(1024), dim3(kExpandThreads), 0, s, x, (const u32 *)t.defer_list, t.defer_count, t.defer_capacity);
+    hipLaunchKernelGGL(decode_expand_list_kernel, dim3(512), dim3(kExpandThreads), 0, s, x, (const u64 *)t.defer_list, (const u32 *)t.defer_count, t.defer_capacity);
     return hipGetLastError();
 }
 

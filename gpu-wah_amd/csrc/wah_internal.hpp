@@ -31,9 +31,12 @@ constexpr uint32_t kCtlClearDone = 96;   // tile kernels: == kCtlWraps + 1 once 
 constexpr uint32_t kCtlError = 160;      // sticky error bits
 constexpr uint32_t kCtlResult = 162;     // host-pointer entry points: two 64-bit results of the launch live here, beside the
                                          // error word, so that ONE 32-byte copy brings status and sizes to the host
-constexpr uint32_t kCtlDefer = 192;      // one-pass decoder: [0] tiles on its list of deferred tiles, [1] workgroups of the list's launch that are
-                                         // done (which then zeroes both).  HERE, not beside the list: where the list lies depends on the size of the
-                                         // workspace a call names, and a counter at a place that moves would be found holding an earlier call's data
+constexpr uint32_t kCtlDefer = 192;      // one-pass decoder, its list of deferred tiles: [0], [1] two counters of entries used in turn, [2] the
+                                         // number of one-pass launches so far (launch s counts in [s & 1]; its last batch zeroes the other
+                                         // counter -- nobody reads that one any more -- and stores s + 1: the launch over the list needs no
+                                         // atomics to hand the counters back).  HERE, not beside the list: where the list lies depends on the
+                                         // size of the workspace a call names, and a counter at a place that moves would be found holding an
+                                         // earlier call's data
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
 constexpr uint32_t kErrTimeout = 1u;     // a bounded wait expired
 constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity
@@ -181,7 +184,7 @@ hipError_t launch_bitop_check(const uint64_t *info_a, const uint64_t *info_b, co
                               uint32_t *ctrl, hipStream_t s);
 hipError_t launch_decode_sums(const ScanArgs &a, hipStream_t s);
 hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t n_tiles, hipStream_t s);
-hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, uint32_t *defer, hipStream_t s); // one pass: decode_tile_kernel
+hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, uint64_t *defer, hipStream_t s); // one pass: decode_tile_kernel
 constexpr uint32_t kDecodeTileWords = 2 * kScanTileWords; // ... whose workgroup tiles are this long
 hipError_t launch_clear(void *p, size_t bytes, hipStream_t s);
 hipError_t launch_build_index(const uint32_t *comp, uint64_t c_words, const uint64_t *tile_base, const uint64_t *info, uint64_t *offsets,

@@ -689,6 +689,25 @@ def test_workspace_serves_different_sizes_in_turn(wah, oracle):
         assert np.array_equal(_host(dec.result())[:n], data), n
 
 
+def test_decode_long_fills_inside_dense_data(wah, oracle):
+    """Incompressible data with long holes: the stream is short enough against its output for the one-pass decoder, whose
+    tiles with a giant fill (thousands of output segments out of one word) go to the second launch in parts."""
+    n = 992 * 9000
+    x = oracle.gen_uniform(n, 77, 0.5)
+    x[992 * 100 + 5: 992 * 2100 - 7] = 0                      # 2000 segments of zeros
+    x[992 * 4000: 992 * 4000 + 40] = 0xFFFFFFFF                # a short run of ones
+    x[992 * 6000 + 1: 992 * 7500] = 0xFFFFFFFF                 # 1500 segments of ones
+    x[992 * 8000: 992 * 8300] = oracle.gen_clustered(992 * 300, 78)  # a clustered stretch: tiles that expand 60 x
+    st = oracle.compress(x)
+    assert (n + 1) // 8 <= len(st)                              # (the one-pass route's condition)
+    back = _host(wah.decompress_device(_dev(st), n + 1))
+    assert np.array_equal(back[:n], x)
+    # ... and the classic form of the same bitmap (fills that cross segments: two giant words)
+    un = _py_merge_fills(st)
+    back = _host(wah.decompress_device(_dev(un), n + 1))
+    assert np.array_equal(back[:n], x)
+
+
 def test_decode_workspace_named_with_different_sizes(wah, oracle):
     """One decode workspace BUFFER, handed over with the size each stream needs (what the host entry points do with the
     buffer they keep): the areas behind the control block then lie elsewhere from call to call, and nothing in them may be
