@@ -90,7 +90,7 @@ DecodeLayout decode_layout(uint64_t c_words, size_t workspace_bytes = 0) {
     const size_t scan_need = blocks * wah::kSumScanBlockWords * sizeof(uint32_t);
     const size_t base_bytes = round256((l.n_tiles + 4) * sizeof(uint64_t)); // (+ two words for wah_validate_device)
     const size_t flag_bytes = round256(l.n_tiles + 16);                       // one byte per tile: contains empty fills
-    const size_t rest_need = base_bytes + flag_bytes + round256((l.n_tiles + c_words / 3968 + 2 + 64) * sizeof(uint64_t)); // + deferred tiles (launch_decode_tiles)
+    const size_t rest_need = base_bytes + flag_bytes + round256((size_t)wah::decode_defer_capacity(l.n_tiles, c_words) * 2 * sizeof(uint64_t)); // + the list of deferred / shared-out tiles
     const size_t need_half = round256(scan_need > rest_need ? scan_need : rest_need);
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
@@ -609,7 +609,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
             set_err("clearing the workspace", e);
             return WAH_ERR_HIP;
         }
-        wah::ScanArgs a;
+        wah::ScanArgs a{};
         a.comp = d_comp;
         a.c_words = c_words;
         a.n_tiles = l.n_tiles;
@@ -622,7 +622,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         a.aligned16 = 1;
         a.host_result = host_result;
         a.no_wait = 0;
-        wah::ExpandArgs x;
+        wah::ExpandArgs x{};
         x.comp = d_comp;
         x.c_words = c_words;
         x.out = d_out;
@@ -651,7 +651,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
             return WAH_ERR_HIP;
         }
         if (c_words) {
-            wah::ScanArgs a;
+            wah::ScanArgs a{};
             a.comp = d_comp;
             a.c_words = c_words;
             a.n_tiles = l.n_tiles;
@@ -664,6 +664,8 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
             a.aligned16 = aligned16(d_comp) ? 1 : 0;
             a.host_result = host_result;
             a.no_wait = no_wait ? 1 : 0;
+            a.defer_list = reinterpret_cast<uint64_t *>(ws + l.defer_off);
+            a.defer_capacity = wah::decode_defer_capacity(l.n_tiles, c_words);
             e = wah::launch_decode_sums(a, s);
             if (e != hipSuccess) {
                 set_err("decode sums kernel launch", e);
@@ -673,7 +675,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
     }
     if (c_words == 0) return WAH_OK;
     if (do_expand) {
-        wah::ExpandArgs x;
+        wah::ExpandArgs x{};
         x.comp = d_comp;
         x.c_words = c_words;
         x.out = d_out;
@@ -684,6 +686,9 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         x.ctrl = reinterpret_cast<uint32_t *>(ws + l.ctrl_off);
         x.aligned16 = aligned16(d_comp) ? 1 : 0;
         x.parts = 1; // the launcher decides
+        x.defer_list = reinterpret_cast<const uint64_t *>(ws + l.defer_off);
+        x.defer_count = reinterpret_cast<const uint32_t *>(ws + l.ctrl_off) + wah::kCtlDefer;
+        x.defer_capacity = wah::decode_defer_capacity(l.n_tiles, c_words);
         e = wah::launch_decode_expand(x, l.n_tiles, s);
         if (e != hipSuccess) {
             set_err("decode expand kernel launch", e);

@@ -195,6 +195,33 @@ __device__ __forceinline__ u64 sums_resolve(u32 *ctrl, u32 *gen_desc, u32 wt, u3
     return base;
 }
 
+// The counters of the list (wah_internal.hpp, kCtlDefer) at the end of a launch that may have appended -- one lane, after
+// every workgroup of the launch has read which counters are the launch's: the other ones are zeroed for the next launch
+// (nobody reads them any more), these are handed to whoever walks the list.
+__device__ __forceinline__ void defer_counters_next(u32 *c) {
+    const u32 seq = __hip_atomic_load(c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c + ((seq + 1u) & 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c + 3u + ((seq + 1u) & 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c + 2, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One expand tile onto the list of tiles that are decoded by workgroups of their own (the one-pass decoder's second launch,
+// the launch behind decode_expand_kernel).  An entry = {tile, parts} {sum of the parts of the entries before it}: the tile's
+// output segments are shared out over `parts` workgroups of that launch, one per 64 segments (a long fill inside otherwise
+// incompressible data: millions of groups out of one word), workgroup (sum + p) mod G taking part p -- so the list holds
+// ONE entry per tile whatever the size of the output, and the launch's workgroups get equal shares whatever the mix of
+// tiles.  c = the launch's counters (kCtlDefer + (launch & 1)).  false: the list is full (the tile is not on it).
+__device__ __forceinline__ bool dt_defer(u32 *c, u64 *list, u32 capacity, u64 tile, u64 groups) {
+    const u64 segs = groups / kSegGroups + 2ull;
+    const u32 parts = segs >= 64ull * 4096ull ? 4096u : (u32)((segs + 63ull) / 64ull);
+    const u32 slot = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (slot >= capacity) return false; // (also: a counter that did not start at zero must not lead outside the list)
+    const u32 before = __hip_atomic_fetch_add(c + 3, parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    list[2ull * slot] = tile | ((u64)parts << 32);
+    list[2ull * slot + 1] = before;
+    return true;
+}
+
 // kWaveTiles: expand tiles a wavefront sums one after the other (long streams: 4, so that ticket, barrier and scan are
 // paid once per 128 KiB... 512 KiB of stream; short streams: 1, more workgroups)
 // kNoWait: the first launch of the NO-WAIT route (WAH_NO_WAIT / WAH_FORCE_FALLBACK=1, and what decompress() takes by
@@ -204,6 +231,7 @@ __device__ __forceinline__ u64 sums_resolve(u32 *ctrl, u32 *gen_desc, u32 wt, u3
 template <u32 kWaveTiles, bool kNoWait = false>
 __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanArgs a) {
     __shared__ u64 s_part[kSumWaves * kWaveTiles];
+    __shared__ u32 s_empty[kSumWaves * kWaveTiles];
     __shared__ u32 s_tile;
 
     const u32 lane = lane_id();
@@ -283,7 +311,7 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
             const bool any_empty = __any(has_empty);
             if (lane == 0) {
                 s_part[wave * kWaveTiles + rd / 4u] = tile_total;
-                if (et < n_tiles) a.tile_flags[et] = any_empty ? 1 : 0;
+                s_empty[wave * kWaveTiles + rd / 4u] = any_empty ? 1u : 0u;
             }
             mine = 0;
             has_empty = false;
@@ -295,6 +323,17 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
     // ---- wave 0: the workgroup tile's total goes out, then the groups in front of it ---------------------------------
     static_assert(kSumWaves * kWaveTiles <= 64, "one lane per expand tile of the workgroup tile");
     const u64 part = lane < kSumWaves * kWaveTiles ? s_part[lane] : 0ull;
+    // lane w: expand tile et0 + w (wave 0: et0 = the workgroup tile's first expand tile).  A tile that expands to very many
+    // segments is not left to the `parts` workgroups the expand launch gives every tile alike (a hole of 100 000 segments in
+    // otherwise dense data: 26 ms in one workgroup): onto the list with it, 32 segments per entry, and bit 1 of its flags.
+    if (lane < kSumWaves * kWaveTiles && et0 + lane < n_tiles) {
+        bool listed = false;
+        if (a.defer_list && part / kSegGroups > kListSegs) {
+            u32 *const count = a.ctrl + kCtlDefer + (__hip_atomic_load(a.ctrl + kCtlDefer + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
+            listed = dt_defer(count, a.defer_list, a.defer_capacity, et0 + lane, part);
+        }
+        a.tile_flags[et0 + lane] = (uint8_t)(s_empty[lane] | (listed ? 2u : 0u));
+    }
     if (kNoWait) { // totals only (wave 0: et0 = the workgroup tile's first expand tile); sums_offsets_kernel does the rest
         if (lane < kSumWaves * kWaveTiles && et0 + lane < n_tiles) a.tile_base[et0 + lane] = part < kSumSaturate ? part : kSumSaturate;
         return;
@@ -320,6 +359,7 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
                 a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
             }
             launch_epoch_end(a.ctrl, le);
+            if (a.defer_list) defer_counters_next(a.ctrl + kCtlDefer);
         }
     }
 }
@@ -625,7 +665,7 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     const u64 out_words = a.info[0];
     // (asked for up front, used after the prologue: this tile or the next one contains fill words of count 0)
     const u64 all_tiles = (a.c_words + kScanTileWords - 1) / kScanTileWords;
-    const bool has_empties = (a.tile_flags[tile] | ((u64)tile + 1 < all_tiles ? a.tile_flags[tile + 1] : 0)) != 0;
+    const bool has_empties = ((a.tile_flags[tile] | ((u64)tile + 1 < all_tiles ? a.tile_flags[tile + 1] : 0)) & 1) != 0;
     if (out_words > a.out_capacity) {
         if (threadIdx.x == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
         return;
@@ -708,7 +748,7 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
 #ifdef WAH_DIAG
     __syncthreads();
     if (wave == 0 && lane == 0 && tile % 67u == 0u) { // a sample (tools/decode_phases.py): 100 MHz stamps
-        unsigned long long *d = reinterpret_cast<unsigned long long *>(a.ctrl + 192);
+        unsigned long long *d = reinterpret_cast<unsigned long long *>(a.ctrl + 224); // (192..194: kCtlDefer)
         const u64 now = __builtin_amdgcn_s_memrealtime();
         atomicAdd(d + 0, (unsigned long long)(dg_ready - dg_start)); // tile staged, coarse prefix built
         atomicAdd(d + 1, (unsigned long long)(now - dg_ready));      // the tile's segments expanded
@@ -717,28 +757,40 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
 #endif
 }
 
-// a stream of few tiles (highly compressed data) expands to many segments per tile: `parts` workgroups share a tile
+// the tiles on the list (dt_defer): workgroup w of G takes part p of an entry iff (its sum + p) mod G == w
+__device__ __forceinline__ void expand_list(const ExpandArgs &a, const u64 *list, const u32 *count, u32 capacity, u32 w, u32 G) {
+    // a workspace that the launch before refused (WAH_ERR_WORKSPACE: neither zeroed nor left by a launch) holds no list
+    if (__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kErrWorkspace) return;
+    const u64 n_et = (a.c_words + kScanTileWords - 1) / kScanTileWords;
+    // the counter of the launch that has just ended (count[2] = launches so far; wah_internal.hpp, kCtlDefer): read only --
+    // the NEXT launch that may append zeroes it
+    const u32 seq = uniform32(__hip_atomic_load(count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    u32 n = uniform32(__hip_atomic_load(count + ((seq - 1u) & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (n > capacity) n = capacity; // (whatever the counter holds: every access stays inside the list and the stream)
+    for (u32 i = 0; i < n; ++i) {
+        const u64 e = uniform64(list[2ull * i]), before = uniform64(list[2ull * i + 1]);
+        const u32 tile = (u32)e, parts = (u32)(e >> 32);
+        if (tile >= n_et || parts == 0u || parts > 4096u) continue;
+        for (u32 p = (w + G - (u32)(before % G)) % G; p < parts; p += G) {
+            expand_tile(a, tile, p, parts);
+            __syncthreads(); // the LDS image goes to the next tile
+        }
+    }
+}
+
+// a stream of few tiles (highly compressed data) expands to many segments per tile: `parts` workgroups share a tile; the
+// tiles the sums pass has put on the list (bit 1 of their flags) are left to the launch of decode_expand_list_kernel behind this one
+// (the tile routine inside a loop over list entries takes 125 registers instead of 68: not in this kernel)
 __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const ExpandArgs a) {
-    expand_tile(a, blockIdx.x / a.parts, blockIdx.x % a.parts, a.parts);
+    const u32 tile = blockIdx.x / a.parts;
+    if (a.defer_list && (a.tile_flags[tile] & 2)) return; // (on the list: decode_expand_list_kernel, the launch behind this one)
+    expand_tile(a, tile, blockIdx.x % a.parts, a.parts);
 }
 
 // the expand tiles decode_tile_kernel left to this route (giant fills, fill words of count 0: foreign streams), out of its
 // list; normally the list is empty and the launch ends at once.
 __global__ __launch_bounds__(kExpandThreads) void decode_expand_list_kernel(const ExpandArgs a, const u64 *list, const u32 *count, u32 capacity) {
-    // a workspace that the first launch refused (WAH_ERR_WORKSPACE: neither zeroed nor left by a launch) holds no list
-    if (__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kErrWorkspace) return;
-    const u64 n_et = (a.c_words + kScanTileWords - 1) / kScanTileWords;
-    // the counter of the launch that has just ended (count[2] = launches so far; wah_internal.hpp, kCtlDefer): read only --
-    // the NEXT one-pass launch zeroes it
-    const u32 seq = uniform32(__hip_atomic_load(count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    u32 n = uniform32(__hip_atomic_load(count + ((seq - 1u) & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (n > capacity) n = capacity; // (whatever the counter holds: every access stays inside the list and the stream)
-    for (u32 i = blockIdx.x; i < n; i += gridDim.x) {
-        const u64 e = uniform64(list[i]); // {tile:32, part:16, parts:16}: dt_defer
-        const u32 tile = (u32)e, part = (u32)(e >> 32) & 0xFFFFu, parts = (u32)(e >> 48);
-        if (tile < n_et && parts != 0u && part < parts) expand_tile(a, tile, part, parts);
-        __syncthreads(); // the LDS image goes to the next tile
-    }
+    expand_list(a, list, count, capacity, blockIdx.x, gridDim.x);
 }
 
 #include "wah_decode_tile.inc"
@@ -912,6 +964,7 @@ __global__ __launch_bounds__(1024) void sums_offsets_kernel(const ScanArgs a) {
             a.host_result[2] = end;
             a.host_result[0] = 1ull | ((u64)__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32);
         }
+        if (a.defer_list) defer_counters_next(a.ctrl + kCtlDefer);
     }
 }
 
@@ -950,7 +1003,13 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
     if (parts < 1) parts = 1;
     if (parts > 1024) parts = 1024;
     a.parts = (u32)parts;
+    a.n_tile_wgs = (u32)(n_tiles * parts);
     hipLaunchKernelGGL(decode_expand_kernel, dim3((unsigned)(n_tiles * parts)), dim3(kExpandThreads), 0, s, a);
+    if (a.defer_list) { // the tiles the sums pass listed (normally none: the launch ends at once)
+        ExpandArgs x = a;
+        x.parts = 1;
+        hipLaunchKernelGGL(decode_expand_list_kernel, dim3(512), dim3(kExpandThreads), 0, s, x, a.defer_list, a.defer_count, a.defer_capacity);
+    }
     return hipGetLastError();
 }
 
@@ -971,7 +1030,7 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *de
     t.tile_flags = sa.tile_flags;
     t.defer_count = sa.ctrl + kCtlDefer; // (wah_internal.hpp)
     t.defer_list = defer;
-    t.defer_capacity = (u32)(sa.n_tiles + sa.c_words / 3968u + 2u); // (decode_layout; dt_defer: one entry per tile + one per 32 segments of output, and the output is at most 8 x the stream)
+    t.defer_capacity = decode_defer_capacity(sa.n_tiles, sa.c_words);
     t.ctrl = sa.ctrl;
     t.gen_desc = sa.gen_desc;
     t.scan_words = sa.scan_words;
@@ -982,6 +1041,7 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *de
         hipLaunchKernelGGL(decode_tile_kernel<2>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t);
     ExpandArgs x = xa;
     x.parts = 1;
+    x.defer_list = nullptr; // (the list is this launch's own argument)
     hipLaunchKernelGGL(decode_expand_list_kernel, dim3(512), dim3(kExpandThreads), 0, s, x, (const u64 *)t.defer_list, (const u32 *)t.defer_count, t.defer_capacity);
     return hipGetLastError();
 }

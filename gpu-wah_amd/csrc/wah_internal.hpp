@@ -31,12 +31,13 @@ constexpr uint32_t kCtlClearDone = 96;   // tile kernels: == kCtlWraps + 1 once 
 constexpr uint32_t kCtlError = 160;      // sticky error bits
 constexpr uint32_t kCtlResult = 162;     // host-pointer entry points: two 64-bit results of the launch live here, beside the
                                          // error word, so that ONE 32-byte copy brings status and sizes to the host
-constexpr uint32_t kCtlDefer = 192;      // one-pass decoder, its list of deferred tiles: [0], [1] two counters of entries used in turn, [2] the
-                                         // number of one-pass launches so far (launch s counts in [s & 1]; its last batch zeroes the other
-                                         // counter -- nobody reads that one any more -- and stores s + 1: the launch over the list needs no
-                                         // atomics to hand the counters back).  HERE, not beside the list: where the list lies depends on the
-                                         // size of the workspace a call names, and a counter at a place that moves would be found holding an
-                                         // earlier call's data
+constexpr uint32_t kCtlDefer = 192;      // the decoders' list of tiles that are decoded by workgroups of their own: [0], [1] two counters of
+                                         // entries used in turn, [2] the number of launches that could append so far (launch s counts in
+                                         // [s & 1]; its last tile zeroes the other counters -- nobody reads them any more -- and stores
+                                         // s + 1: whoever walks the list needs no atomics to hand the counters back), [3], [4] the sum of
+                                         // the entries' parts, in turn like [0], [1].  HERE, not beside the list: where the list lies depends
+                                         // on the size of the workspace a call names, and a counter at a place that moves would be found
+                                         // holding an earlier call's data
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
 constexpr uint32_t kErrTimeout = 1u;     // a bounded wait expired
 constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity
@@ -116,11 +117,20 @@ struct ScanArgs {
     uint32_t *ctrl;
     uint32_t *gen_desc;  // scan area: blocks of kSumScanBlockWords (see decode_sums_kernel)
     uint64_t scan_words; // 32-bit words of the whole scan area
-    uint8_t *tile_flags; // n_tiles: 1 = the tile contains a fill word of count 0
+    uint8_t *tile_flags; // n_tiles: bit 0 = the tile contains a fill word of count 0, bit 1 = it is on defer_list
     int aligned16;
     uint64_t *host_result; // optional, page-locked HOST memory: [0] = 1 | error bits << 32, [1..2] = info, by the last tile
     int no_wait;           // 1: the no-wait route (per-tile totals, then one scan launch): nobody waits for anybody
+    uint64_t *defer_list;  // optional: tiles that expand to more than kListSegs segments go onto this list (dt_defer) and
+    uint32_t defer_capacity; // are left to the expand launch's list workgroups; their tile_flags get bit 1
 };
+constexpr uint32_t kListSegs = 1024; // (a tile of 4096 words that expands to more than a million groups)
+// entries (16 bytes each) the list of deferred / shared-out tiles has room for: a tile goes onto it once at most, the
+// one-pass decoder may add the tile of a tile's last segment once more
+inline uint32_t decode_defer_capacity(uint64_t n_tiles, uint64_t) {
+    const uint64_t n = 2 * n_tiles + 64;
+    return n > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n;
+}
 
 struct ExpandArgs {
     const uint32_t *comp;
@@ -129,10 +139,14 @@ struct ExpandArgs {
     uint64_t out_capacity;
     const uint64_t *info;
     const uint64_t *tile_base;
-    const uint8_t *tile_flags; // from the sums pass: tiles with fill words of count 0
+    const uint8_t *tile_flags; // from the sums pass: bit 0 = the tile has fill words of count 0, bit 1 = it is on the list
     uint32_t *ctrl;
     int aligned16;
     uint32_t parts; // workgroups that share one tile's output segments (set by the launcher)
+    const uint64_t *defer_list; // optional: the list the sums pass left (ScanArgs::defer_list), shared out over the launch's workgroups
+    const uint32_t *defer_count; // control block, kCtlDefer
+    uint32_t defer_capacity;
+    uint32_t n_tile_wgs;        // workgroups in front of them: tiles x parts (set by the launcher)
 };
 
 // wah_decompress_segments_device: decode a range of segments through the index of wah_compress_device_indexed

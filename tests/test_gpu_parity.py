@@ -708,6 +708,28 @@ def test_decode_long_fills_inside_dense_data(wah, oracle):
     assert np.array_equal(back[:n], x)
 
 
+def test_decode_mostly_empty_bitmap_with_dense_islands(wah, oracle):
+    """Classic (unsegmented) WAH of a mostly empty bitmap: a short stream -- the two-launch route -- whose tiles around the
+    islands hold fills of millions of groups.  Those tiles are put on a list by the sums pass and shared out over the
+    workgroups of a launch of their own (one workgroup used to expand such a tile alone: 3.6 ms for this shape at 1 GiB,
+    0.25 ms now); here the parity of that path, scan and no-wait routes."""
+    import torch
+
+    n = 992 * 40000
+    x = np.zeros(n, np.uint32)
+    x[992 * 9000: 992 * 9300] = oracle.gen_uniform(992 * 300, 5, 0.5)
+    x[992 * 30000 + 7: 992 * 30200] = oracle.gen_uniform(992 * 200 - 7, 6, 0.5)
+    x[992 * 39000:] = 0xFFFFFFFF
+    st = _py_merge_fills(oracle.compress(x))
+    assert len(st) * 8 < n  # (highly compressed: not the one-pass decoder's case)
+    for no_wait in (False, True):
+        dec = wah.DeviceDecompressor(len(st), n + 1, no_wait=no_wait)
+        dec.run(_dev(st))
+        assert np.array_equal(_host(dec.result())[:n], x), no_wait
+        dec.run(_dev(st))  # (the list's counters change hands from launch to launch)
+        assert np.array_equal(_host(dec.result())[:n], x), no_wait
+
+
 def test_decode_workspace_named_with_different_sizes(wah, oracle):
     """One decode workspace BUFFER, handed over with the size each stream needs (what the host entry points do with the
     buffer they keep): the areas behind the control block then lie elsewhere from call to call, and nothing in them may be

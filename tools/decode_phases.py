@@ -21,13 +21,13 @@ for kind in sys.argv[1:] or ["sparse", "dense"]:
     dec = wah.DeviceDecompressor(comp.capacity, n + 1)
     dec.run(comp.out, c)
     dec.status()
-    dec.workspace[768:1024].zero_()
+    dec.workspace[896:1024].zero_()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ev[0].record()
     dec.run(comp.out, c)
     ev[1].record()
     dec.status()
-    acc = dec.workspace[768:1024].view(torch.int64).cpu().tolist()
+    acc = dec.workspace[896:1024].view(torch.int64).cpu().tolist()
     tiles = max(acc[2], 1)
     print(f"--- {kind}: {tiles} sampled tiles, sums + expand {ev[0].elapsed_time(ev[1]):.3f} ms (diag build)")
     print(f"   tile staged + coarse prefix {acc[0] / tiles / 100.0:6.2f} us/tile")
