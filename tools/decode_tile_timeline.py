@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Time line of decode_tile_kernel (DIAGNOSTIC build: the stamps overwrite the head of the output buffer): per tile, when it
-started, had its words staged, published its total, had its start flags, knew its base, finished (s_memrealtime, 100 MHz).
+"""Time line of decode_tile_kernel (DIAGNOSTIC build: the stamps overwrite the head of the output buffer): per workgroup = per
+BATCH of tiles (two tiles of 8192 words; WAH_DT_BATCH=1: one), when it started, had its last tile staged and all of them counted,
+published its total, had the first tile's start flags, knew its base, finished (s_memrealtime, 100 MHz).
 usage: python tools/decode_tile_timeline.py [sparse|dense ...]"""
 import importlib
 import os
@@ -25,20 +26,21 @@ for kind in sys.argv[1:] or ["sparse"]:
     dec.status()
     dec.run(stream)
     dec.status()
-    n_tiles = (stream.numel() + 8191) // 8192
+    batch = 1 if os.environ.get("WAH_DT_BATCH") == "1" else 2
+    n_tiles = (stream.numel() + 8192 * batch - 1) // (8192 * batch)  # workgroups
     t = dec.out[: n_tiles * 16].view(torch.int64).cpu().numpy().reshape(n_tiles, 8)
     start, staged, pub, flags, base, bar3, end, segs = (t[:, i] for i in range(8))
     t0 = start.min()
     us = lambda x: x / 100.0
     q = lambda x: f"{us(x.mean()):.2f} (p10 {us(np.percentile(x, 10)):.2f}, p90 {us(np.percentile(x, 90)):.2f})"
-    print(f"--- {kind}: {n_tiles} tiles of 8192 words, {segs.mean():.1f} segments per tile, span {us(end.max() - t0):.1f} us")
-    print(f"   start -> words staged            {q(staged - start)}")
-    print(f"   -> counted, barrier 1 (publish)  {q(pub - staged)}")
-    print(f"   -> start flags, barrier 2        {q(flags - pub)}")
-    print(f"   -> base known (wave 0)           {q(base - flags)}")
-    print(f"   -> barrier 3                     {q(bar3 - base)}")
-    print(f"   -> segments expanded, end        {q(end - bar3)}")
-    print(f"   tile life                        {q(end - start)}")
+    print(f"--- {kind}: {n_tiles} workgroups of {batch} x 8192 words, span {us(end.max() - t0):.1f} us")
+    print(f"   start -> all tiles counted, the last one staged {q(staged - start)}")
+    print(f"   -> barrier 1 (publish)                          {q(pub - staged)}")
+    print(f"   -> the first tile's start flags, barrier 2      {q(flags - pub)}")
+    print(f"   -> base known (wave 0)                          {q(base - flags)}")
+    print(f"   -> barrier 3                                    {q(bar3 - base)}")
+    print(f"   -> all tiles expanded, end                      {q(end - bar3)}")
+    print(f"   life of the workgroup                           {q(end - start)}")
     s = us(start - t0)
     e = us(end - t0)
     for x in np.arange(0, e.max() + 50, 50.0):
