@@ -29,10 +29,15 @@ for kind in sys.argv[1:] or ["sparse"]:
     batch = 1 if os.environ.get("WAH_DT_BATCH") == "1" else 2
     n_tiles = (stream.numel() + 8192 * batch - 1) // (8192 * batch)  # workgroups
     t = dec.out[: n_tiles * 16].view(torch.int64).cpu().numpy().reshape(n_tiles, 8)
+    # (the stamps lie where the first workgroups' output goes: rows that were written over afterwards are dropped)
+    life = t[:, 6] - t[:, 0]
+    keep = (life > 0) & (life < 100_000_000) & (t[:, 1] >= t[:, 0]) & (t[:, 6] >= t[:, 5])
+    print(f"({int(keep.sum())} of {n_tiles} rows kept)")
+    t = t[keep]
     start, staged, pub, flags, base, bar3, end, segs = (t[:, i] for i in range(8))
     t0 = start.min()
     us = lambda x: x / 100.0
-    q = lambda x: f"{us(x.mean()):.2f} (p10 {us(np.percentile(x, 10)):.2f}, p90 {us(np.percentile(x, 90)):.2f})"
+    q = lambda x: f"{us(np.median(x)):.2f} (p10 {us(np.percentile(x, 10)):.2f}, p90 {us(np.percentile(x, 90)):.2f})"
     print(f"--- {kind}: {n_tiles} workgroups of {batch} x 8192 words, span {us(end.max() - t0):.1f} us")
     print(f"   start -> all tiles counted, the last one staged {q(staged - start)}")
     print(f"   -> barrier 1 (publish)                          {q(pub - staged)}")
