@@ -758,7 +758,15 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
 }
 
 // the tiles on the list (dt_defer): workgroup w of G takes part p of an entry iff (its sum + p) mod G == w
-__device__ __forceinline__ void expand_list(const ExpandArgs &a, const u64 *list, const u32 *count, u32 capacity, u32 w, u32 G) {
+// regular_parts: the parts decode_expand_kernel gives every tile, 0 = none (the one-pass decoder's list): a listed tile whose
+// share per workgroup is at most 256 segments there has been expanded there (short streams: `parts` is large, and a stream
+// whose tiles all expand alike is spread well by `parts` alone -- the list's launch has fewer workgroups)
+__device__ __forceinline__ bool listed_tile_is_regular(const ExpandArgs &a, u32 tile, u32 regular_parts) {
+    if (regular_parts == 0u) return false;
+    const u64 segs = (a.tile_base[tile + 1] - a.tile_base[tile]) / kSegGroups;
+    return segs <= 256ull * regular_parts;
+}
+__device__ __forceinline__ void expand_list(const ExpandArgs &a, const u64 *list, const u32 *count, u32 capacity, u32 w, u32 G, u32 regular_parts) {
     // a workspace that the launch before refused (WAH_ERR_WORKSPACE: neither zeroed nor left by a launch) holds no list
     if (__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kErrWorkspace) return;
     const u64 n_et = (a.c_words + kScanTileWords - 1) / kScanTileWords;
@@ -767,13 +775,29 @@ __device__ __forceinline__ void expand_list(const ExpandArgs &a, const u64 *list
     const u32 seq = uniform32(__hip_atomic_load(count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     u32 n = uniform32(__hip_atomic_load(count + ((seq - 1u) & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     if (n > capacity) n = capacity; // (whatever the counter holds: every access stays inside the list and the stream)
-    for (u32 i = 0; i < n; ++i) {
-        const u64 e = uniform64(list[2ull * i]), before = uniform64(list[2ull * i + 1]);
-        const u32 tile = (u32)e, parts = (u32)(e >> 32);
-        if (tile >= n_et || parts == 0u || parts > 4096u) continue;
-        for (u32 p = (w + G - (u32)(before % G)) % G; p < parts; p += G) {
-            expand_tile(a, tile, p, parts);
-            __syncthreads(); // the LDS image goes to the next tile
+    // 64 entries at a time, one per lane: which of them have a part for this workgroup at all (most have none: an entry of
+    // few parts concerns few workgroups, and one whose tile `parts` spreads well enough concerns nobody)
+    const u32 lane = lane_id();
+    for (u32 i0 = 0; i0 < n; i0 += 64u) {
+        const u32 i = i0 + lane;
+        u64 e = 0, before = 0;
+        if (i < n) {
+            e = list[2ull * i];
+            before = list[2ull * i + 1];
+        }
+        const u32 tile_l = (u32)e, parts_l = (u32)(e >> 32);
+        const u32 first_l = (w + G - (u32)(before % G)) % G; // my first part of the entry (if it has that many)
+        bool mine = i < n && tile_l < n_et && parts_l != 0u && parts_l <= 4096u && first_l < parts_l;
+        if (mine && listed_tile_is_regular(a, tile_l, regular_parts)) mine = false;
+        u64 m = __ballot(mine);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const u32 tile = (u32)__builtin_amdgcn_readlane((int)tile_l, l), parts = (u32)__builtin_amdgcn_readlane((int)parts_l, l);
+            for (u32 p = (u32)__builtin_amdgcn_readlane((int)first_l, l); p < parts; p += G) {
+                expand_tile(a, tile, p, parts);
+                __syncthreads(); // the LDS image goes to the next tile
+            }
         }
     }
 }
@@ -783,14 +807,19 @@ __device__ __forceinline__ void expand_list(const ExpandArgs &a, const u64 *list
 // (the tile routine inside a loop over list entries takes 125 registers instead of 68: not in this kernel)
 __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const ExpandArgs a) {
     const u32 tile = blockIdx.x / a.parts;
-    if (a.defer_list && (a.tile_flags[tile] & 2)) return; // (on the list: decode_expand_list_kernel, the launch behind this one)
+    // (on the list and too much for `parts` workgroups: decode_expand_list_kernel, the launch behind this one)
+    if (a.defer_list && (a.tile_flags[tile] & 2) && !listed_tile_is_regular(a, tile, a.parts)) {
+        // (an output that does not fit is reported all the same: the list's launch is left out when the CAPACITY is small)
+        if (threadIdx.x == 0 && a.info[0] > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+        return;
+    }
     expand_tile(a, tile, blockIdx.x % a.parts, a.parts);
 }
 
 // the expand tiles decode_tile_kernel left to this route (giant fills, fill words of count 0: foreign streams), out of its
 // list; normally the list is empty and the launch ends at once.
-__global__ __launch_bounds__(kExpandThreads) void decode_expand_list_kernel(const ExpandArgs a, const u64 *list, const u32 *count, u32 capacity) {
-    expand_list(a, list, count, capacity, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(kExpandThreads) void decode_expand_list_kernel(const ExpandArgs a, const u64 *list, const u32 *count, u32 capacity, u32 regular_parts) {
+    expand_list(a, list, count, capacity, blockIdx.x, gridDim.x, regular_parts);
 }
 
 #include "wah_decode_tile.inc"
@@ -1005,10 +1034,12 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
     a.parts = (u32)parts;
     a.n_tile_wgs = (u32)(n_tiles * parts);
     hipLaunchKernelGGL(decode_expand_kernel, dim3((unsigned)(n_tiles * parts)), dim3(kExpandThreads), 0, s, a);
-    if (a.defer_list) { // the tiles the sums pass listed (normally none: the launch ends at once)
+    // the tiles the sums pass listed and `parts` workgroups are not enough for (normally none: the launch ends at once; no tile
+    // can be one when the whole output is no more than 256 segments per part: short streams do without the launch)
+    if (a.defer_list && a.out_capacity / kSegWords > 256ull * parts) {
         ExpandArgs x = a;
         x.parts = 1;
-        hipLaunchKernelGGL(decode_expand_list_kernel, dim3(512), dim3(kExpandThreads), 0, s, x, a.defer_list, a.defer_count, a.defer_capacity);
+        hipLaunchKernelGGL(decode_expand_list_kernel, dim3(512), dim3(kExpandThreads), 0, s, x, a.defer_list, a.defer_count, a.defer_capacity, a.parts);
     }
     return hipGetLastError();
 }
@@ -1042,7 +1073,7 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *de
     ExpandArgs x = xa;
     x.parts = 1;
     x.defer_list = nullptr; // (the list is this launch's own argument)
-    hipLaunchKernelGGL(decode_expand_list_kernel, dim3(512), dim3(kExpandThreads), 0, s, x, (const u64 *)t.defer_list, (const u32 *)t.defer_count, t.defer_capacity);
+    hipLaunchKernelGGL(decode_expand_list_kernel, dim3(512), dim3(kExpandThreads), 0, s, x, (const u64 *)t.defer_list, (const u32 *)t.defer_count, t.defer_capacity, 0u);
     return hipGetLastError();
 }
 
