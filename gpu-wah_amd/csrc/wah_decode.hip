@@ -403,7 +403,7 @@ __device__ __forceinline__ void expand_steps(const ExpandArgs &a, const u32 *s_w
     asm volatile("" : "+v"(soff));
     const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
     const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
-    u32 before4 = (first_word - 1u) * 4u;                 // byte offset of (first_word + flags in earlier steps - 1)
+    u32 before4 = (uniform32(first_word) - 1u) * 4u;      // byte offset of (first_word + flags in earlier steps - 1): scalar
     // four steps at a time: their ranks first, then the four gathers together, then decode and store
 #pragma unroll
     for (int g = 0; g < (int)kSteps / 4; ++g) {
@@ -412,9 +412,12 @@ __device__ __forceinline__ void expand_steps(const ExpandArgs &a, const u32 *s_w
         for (int q = 0; q < 4; ++q) {
             const u32 fb = (f[g] >> (8 * q)) & 0xFFu;     // 1: a word starts at my group
             const u64 m = __ballot(fb != 0u);
-            // inclusive rank among this step's flags (the count is seeded with my own flag), plus all earlier ones
-            r4[q] = (__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, fb)) << 2) + before4;
-            before4 = (u32)__builtin_amdgcn_readlane((int)r4[q], 63); // the last lane's rank counts every flag so far
+            // rank among the flags so far = flags at or below my lane = bits of (m >> 1) below my lane (v_mbcnt) + bit 0; the
+            // running count stays on the scalar unit
+            const u64 m1 = m >> 1;
+            const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0u));
+            r4[q] = (below << 2) + (before4 + (((u32)m & 1u) << 2));
+            before4 += (u32)__builtin_popcountll(m) << 2;
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -423,12 +426,12 @@ __device__ __forceinline__ void expand_steps(const ExpandArgs &a, const u32 *s_w
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int s = 4 * g + q;
-            // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354)
-            const u32 fill_val = (u32)((int)(src_word[q] << 1) >> 31) & kOnes31;
-            u32 grp = (int)src_word[q] < 0 ? fill_val : src_word[q];
+            // fill -> 31 copies of bit 30, literal -> itself (kernels.cu:332-354); bit 31 of a fill's group is not cleared: the
+            // repack takes bits 0..30 only
+            u32 grp = (int)src_word[q] < 0 ? (u32)__builtin_amdgcn_sbfe((int)src_word[q], 30, 1) : src_word[q];
             if (!kWhole && (u32)(64 * s) + lane >= nvalid) grp = 0u;
             const u32 hi_part = (u32)__builtin_amdgcn_mov_dpp((int)(grp << up), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-            const u32 word = (grp >> o) | hi_part;
+            const u32 word = __builtin_amdgcn_ubfe(grp, o, 31u - o) | hi_part;
             // (default cache policy: nontemporal stores here cost the clustered round trip 22 % -- the memory-side cache
             //  combines this kernel's 248-byte stores)
             __builtin_amdgcn_raw_buffer_store_b32(word, rsrc, soff + 248u * s, 0, 0);
@@ -1048,7 +1051,7 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
 hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *defer, hipStream_t s) {
     static const u32 batch = [] { // tiles per workgroup: 2 (experiments: WAH_DT_BATCH=1)
         const char *e = std::getenv("WAH_DT_BATCH");
-        return e && e[0] == '1' ? 1u : 2u;
+        return e && e[0] >= '1' && e[0] <= '6' ? (u32)(e[0] - '0') : 2u;
     }();
     TileDecodeArgs t;
     t.comp = sa.comp;
@@ -1066,10 +1069,14 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *de
     t.gen_desc = sa.gen_desc;
     t.scan_words = sa.scan_words;
     t.host_result = sa.host_result;
-    if (batch == 1)
-        hipLaunchKernelGGL(decode_tile_kernel<1>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t);
-    else
-        hipLaunchKernelGGL(decode_tile_kernel<2>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t);
+    switch (batch) {
+    case 1: hipLaunchKernelGGL(decode_tile_kernel<1>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
+    case 3: hipLaunchKernelGGL(decode_tile_kernel<3>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
+    case 4: hipLaunchKernelGGL(decode_tile_kernel<4>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
+    case 5: hipLaunchKernelGGL(decode_tile_kernel<5>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
+    case 6: hipLaunchKernelGGL(decode_tile_kernel<6>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
+    default: hipLaunchKernelGGL(decode_tile_kernel<2>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
+    }
     ExpandArgs x = xa;
     x.parts = 1;
     x.defer_list = nullptr; // (the list is this launch's own argument)

@@ -76,6 +76,10 @@ __device__ __forceinline__ u32 wave_scan_incl32(u32 v) {
     return v;
 }
 
+// sum of a u32 over the 64 lanes as a wave-uniform value, DPP only (wave_sum32's six trips through the LDS crossbar are
+// a chain of six LDS latencies)
+__device__ __forceinline__ u32 wave_total32(u32 v) { return (u32)__builtin_amdgcn_readlane((int)wave_scan_incl32(v), 63); }
+
 // inclusive prefix MAXIMUM of a u32 across the 64 lanes, same DPP pattern (missing sources read as 0)
 __device__ __forceinline__ u32 wave_scan_max32(u32 v) {
     v = max(v, (u32)__builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true));

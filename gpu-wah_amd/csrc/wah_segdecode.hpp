@@ -84,10 +84,12 @@ __device__ __forceinline__ bool seg_mark(const SegRange &rg, const u32 (&x0)[kSe
 __device__ __forceinline__ u32 seg_group(int s, const u32 (&f)[4], u32 &before, const u32 *words, u32 cnt, u32 nvalid, u32 lane) {
     const u32 fb = (f[s >> 2] >> (8 * (s & 3))) & 0xFFu;
     const u64 m = __ballot(fb != 0u);
-    const u32 r = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, fb)) + before;
-    before = (u32)__builtin_amdgcn_readlane((int)r, 63);
+    // flags at or below my lane = bits of (m >> 1) below my lane (v_mbcnt) + bit 0; the running count is a scalar
+    const u64 m1 = m >> 1;
+    const u32 r = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0u)) + (before + ((u32)m & 1u));
+    before += (u32)__builtin_popcountll(m);
     const u32 src_word = words[min(r, cnt - 1u)];
-    const u32 fill_val = (u32)((int)(src_word << 1) >> 31) & kOnes31;
+    const u32 fill_val = (u32)__builtin_amdgcn_sbfe((int)src_word, 30, 1) >> 1; // 31 copies of bit 30
     u32 grp = (int)src_word < 0 ? fill_val : src_word;
     if ((u32)(64 * s) + lane >= nvalid) grp = 0u;
     return grp;

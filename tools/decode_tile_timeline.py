@@ -28,13 +28,14 @@ for kind in sys.argv[1:] or ["sparse"]:
     dec.status()
     batch = 1 if os.environ.get("WAH_DT_BATCH") == "1" else 2
     n_tiles = (stream.numel() + 8192 * batch - 1) // (8192 * batch)  # workgroups
-    t = dec.out[: n_tiles * 16].view(torch.int64).cpu().numpy().reshape(n_tiles, 8)
+    t = dec.out[: n_tiles * 32].view(torch.int64).cpu().numpy().reshape(n_tiles, 16)
     # (the stamps lie where the first workgroups' output goes: rows that were written over afterwards are dropped)
     life = t[:, 6] - t[:, 0]
     keep = (life > 0) & (life < 100_000_000) & (t[:, 1] >= t[:, 0]) & (t[:, 6] >= t[:, 5])
     print(f"({int(keep.sum())} of {n_tiles} rows kept)")
     t = t[keep]
-    start, staged, pub, flags, base, bar3, end, segs = (t[:, i] for i in range(8))
+    start, staged, pub, flags, base, bar3, end, _ = (t[:, i] for i in range(8))
+    loop0, setup, seg1, seg2, loop_end, bar4, loop1, nseg = (t[:, i] for i in range(8, 16))
     t0 = start.min()
     us = lambda x: x / 100.0
     q = lambda x: f"{us(np.median(x)):.2f} (p10 {us(np.percentile(x, 10)):.2f}, p90 {us(np.percentile(x, 90)):.2f})"
@@ -45,6 +46,15 @@ for kind in sys.argv[1:] or ["sparse"]:
     print(f"   -> base known (wave 0)                          {q(base - flags)}")
     print(f"   -> barrier 3                                    {q(bar3 - base)}")
     print(f"   -> all tiles expanded, end                      {q(end - bar3)}")
+    two = seg2 > 0
+    print(f"   wave 0, the batch's last tile: barrier 3 -> its segment loop   {q(loop0 - bar3)}")
+    print(f"     first segment: flags, words in front (setup)                 {q(setup - loop0)}")
+    print(f"     first segment: 16 steps issued                               {q(seg1 - setup)}")
+    print(f"     second segment (whole)                                       {q((seg2 - seg1)[two])}   ({int(two.sum())} rows)")
+    print(f"     its segments done ({np.median(nseg):.0f} of them) -> the other waves' too (barrier)  {q(bar4 - loop_end)}")
+    print(f"     whole segment loop of the tile                               {q(loop_end - loop0)}")
+    print(f"     -> the next tile's segment loop (image, flags, counts)       {q((loop1 - bar4)[loop1 > 0])}")
+    print(f"     the next tile's loop -> end                                  {q((end - loop1)[loop1 > 0])}")
     print(f"   life of the workgroup                           {q(end - start)}")
     s = us(start - t0)
     e = us(end - t0)
