@@ -125,6 +125,33 @@ def test_equal_word_counts_per_lane_at_ragged_sizes(wah, oracle, n):
         assert np.array_equal(back[:n], data), (name, n)
 
 
+@pytest.mark.parametrize("words_behind", [0, 1, 2, 63, 64, 1023, 1024, 1151, 1152, 1153, 4095, 4096, 8191])
+def test_decode_stream_ends_around_tile_boundaries(wah, oracle, words_behind):
+    """The one-pass decoder's tiles are 8192 stream words (two per workgroup) and a tile's last segment reads up to 1152
+    words behind it: streams of incompressible words (one group per word) that end `words_behind` words behind a tile, a
+    batch of two tiles, with the last segment lacking groups -- they come out of the fill word of count 0 that the decoder
+    puts behind the stream's end."""
+    for tiles in (1, 2, 3):
+        groups = tiles * 8192 + words_behind
+        for lack in (0, 1, 17):  # bits the bitmap ends in front of a group boundary
+            n = (31 * groups - lack) // 32
+            if n <= 0 or (32 * n + 30) // 31 != groups:
+                continue
+            data = oracle.gen_uniform(n, 7 + tiles, 0.5)
+            stream = oracle.compress(data)
+            assert stream.size == groups  # all literals
+            back = _host(wah.decompress_device(_dev(stream), n + 1))
+            assert back.size in (n, n + 1) and np.array_equal(back[:n], data), (tiles, words_behind, lack)
+            if back.size == n + 1:
+                assert back[n] == 0
+            # the same end behind a long fill: the last tile holds few words
+            mixed = data.copy()
+            mixed[: n // 2] = 0
+            want = oracle.compress(mixed)
+            back = _host(wah.decompress_device(_dev(want), n + 1))
+            assert np.array_equal(back[:n], mixed), (tiles, words_behind, lack, "fill in front")
+
+
 # ---------------------------------------------------------------- distributions
 def _datasets(oracle, n):
     yield "p0.5", oracle.gen_uniform(n, 1337, 0.5)
