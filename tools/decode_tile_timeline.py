@@ -50,7 +50,8 @@ for kind in sys.argv[1:] or ["sparse"]:
     print(f"   wave 0, the batch's last tile: barrier 3 -> its segment loop   {q(loop0 - bar3)}")
     print(f"     first segment: flags, words in front (setup)                 {q(setup - loop0)}")
     print(f"     first segment: 16 steps issued                               {q(seg1 - setup)}")
-    print(f"     second segment (whole)                                       {q((seg2 - seg1)[two])}   ({int(two.sum())} rows)")
+    if two.any():
+        print(f"     second segment (whole)                                       {q((seg2 - seg1)[two])}   ({int(two.sum())} rows)")
     print(f"     its segments done ({np.median(nseg):.0f} of them) -> the other waves' too (barrier)  {q(bar4 - loop_end)}")
     print(f"     whole segment loop of the tile                               {q(loop_end - loop0)}")
     print(f"     -> the next tile's segment loop (image, flags, counts)       {q((loop1 - bar4)[loop1 > 0])}")
