@@ -1051,7 +1051,7 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
 hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *defer, hipStream_t s) {
     static const u32 batch = [] { // tiles per workgroup: 2 (experiments: WAH_DT_BATCH=1)
         const char *e = std::getenv("WAH_DT_BATCH");
-        return e && e[0] >= '1' && e[0] <= '6' ? (u32)(e[0] - '0') : 2u;
+        return e && e[0] == '1' ? 1u : 2u;
     }();
     TileDecodeArgs t;
     t.comp = sa.comp;
@@ -1069,14 +1069,10 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *de
     t.gen_desc = sa.gen_desc;
     t.scan_words = sa.scan_words;
     t.host_result = sa.host_result;
-    switch (batch) {
-    case 1: hipLaunchKernelGGL(decode_tile_kernel<1>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
-    case 3: hipLaunchKernelGGL(decode_tile_kernel<3>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
-    case 4: hipLaunchKernelGGL(decode_tile_kernel<4>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
-    case 5: hipLaunchKernelGGL(decode_tile_kernel<5>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
-    case 6: hipLaunchKernelGGL(decode_tile_kernel<6>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
-    default: hipLaunchKernelGGL(decode_tile_kernel<2>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t); break;
-    }
+    if (batch == 1)
+        hipLaunchKernelGGL(decode_tile_kernel<1>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t);
+    else
+        hipLaunchKernelGGL(decode_tile_kernel<2>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t);
     ExpandArgs x = xa;
     x.parts = 1;
     x.defer_list = nullptr; // (the list is this launch's own argument)

@@ -100,6 +100,19 @@ with open(f"{out}/pmc_sq_counters_sparse.txt", "w") as o:
                     f"waiting (s_waitcnt / barrier) {mean('SQ_WAIT_ANY')/mean('SQ_WAVE_CYCLES'):.2f}\n")
         if c.get("SQ_LDS_IDX_ACTIVE"):
             o.write(f"  LDS bank conflict cycles / LDS active cycles: {mean('SQ_LDS_BANK_CONFLICT')/mean('SQ_LDS_IDX_ACTIVE'):.2f}\n")
+    t = agg.get("decode_tile_kernel", {})
+    if t.get("SQ_INSTS_VALU") and t.get("GRBM_GUI_ACTIVE"):
+        mean = lambda k: sum(t[k]) / len(t[k])
+        segs = 270600.0
+        cycles = mean("GRBM_GUI_ACTIVE") / 8.0
+        o.write(f"== decode_tile_kernel, derived (1 GiB = {int(segs)} output segments, 1024 SIMDs)\n")
+        o.write(f"  instructions per output segment: vector {mean('SQ_INSTS_VALU')/segs:.0f}, scalar {mean('SQ_INSTS_SALU')/segs:.0f}, LDS {mean('SQ_INSTS_LDS')/segs:.0f}, "
+                f"branch {mean('SQ_INSTS_BRANCH')/segs:.0f}, vector memory {(mean('SQ_INSTS_VMEM_RD')+mean('SQ_INSTS_VMEM_WR'))/segs:.1f}\n")
+        o.write(f"  kernel cycles (GRBM_GUI_ACTIVE / 8): {cycles:.0f}\n")
+        per_simd = mean("SQ_INSTS_VALU") / 1024.0
+        o.write(f"  vector instructions per SIMD: {per_simd:.0f}; VALU pipe busy at the 4 cycles a wave64 instruction takes: {4*per_simd/cycles:.2f}\n")
+        o.write(f"  of the wave cycles: issuing {mean('SQ_ACTIVE_INST_ANY')/mean('SQ_WAVE_CYCLES'):.2f}, issue-stalled {mean('SQ_WAIT_INST_ANY')/mean('SQ_WAVE_CYCLES'):.2f}, "
+                f"waiting (s_waitcnt / barrier) {mean('SQ_WAIT_ANY')/mean('SQ_WAVE_CYCLES'):.2f}\n")
     for dk in ("decode_tile_kernel", "decode_expand_kernel"):
       e = agg.get(dk, {})
       if e.get("SQ_LDS_IDX_ACTIVE"):
