@@ -108,6 +108,34 @@ __global__ __launch_bounds__(256) void fill_chunks_once(u32 *out, u32 n_seg) {
     }
 }
 
+// ONE 16-byte store per thread, 4 KiB per workgroup: the launch shape of torch's fill (rocprofv3: 256 x 262144, 4 registers)
+__global__ __launch_bounds__(256) void fill_one_store(u32 *out, u32 n_seg) {
+    const size_t n16 = (size_t)n_seg * kSegWords / 4, i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) reinterpret_cast<u32x4 *>(out)[i] = u32x4{(u32)i, 2, 3, 4};
+}
+// ... the same with one constant in every word (what a fill writes)
+__global__ __launch_bounds__(256) void fill_chunks_const(u32 *out, u32 n_seg) {
+    const size_t n16 = (size_t)n_seg * kSegWords / 4;
+    const u32x4 v = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    u32x4 *o = reinterpret_cast<u32x4 *>(out);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = (size_t)blockIdx.x * 1024u + 256u * k + threadIdx.x;
+        if (i < n16) o[i] = v;
+    }
+}
+// ... and with words that differ from lane to lane and from store to store (what a decoder writes)
+__global__ __launch_bounds__(256) void fill_chunks_mixed(u32 *out, u32 n_seg) {
+    const size_t n16 = (size_t)n_seg * kSegWords / 4;
+    u32x4 *o = reinterpret_cast<u32x4 *>(out);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const size_t i = (size_t)blockIdx.x * 1024u + 256u * k + threadIdx.x;
+        const u32 h = (u32)i * 2654435761u;
+        if (i < n16) o[i] = u32x4{h, h ^ (h >> 7), h * 3u, ~h};
+    }
+}
+
 int main() {
     const u32 n_seg = 270600; // 1 GiB
     u32 *out;
@@ -132,7 +160,10 @@ int main() {
     }
     struct { const char *name; void (*k)(u32 *, u32); u32 grid; } once[] = {
         {"(a) one wavefront per segment, no loop", fill_a_once, (n_seg + 3) / 4}, {"(b) one wavefront per segment, no loop", rows_b_once, (n_seg + 3) / 4},
-        {"16 KiB per workgroup, no loop (torch's fill)", fill_chunks_once, (u32)(((size_t)n_seg * kSegWords / 4 + 1023) / 1024)}};
+        {"16 KiB per workgroup, four stores per thread, no loop", fill_chunks_once, (u32)(((size_t)n_seg * kSegWords / 4 + 1023) / 1024)},
+        {"4 KiB per workgroup, one store per thread", fill_one_store, (u32)(((size_t)n_seg * kSegWords / 4 + 255) / 256)},
+        {"... one constant in every word", fill_chunks_const, (u32)(((size_t)n_seg * kSegWords / 4 + 1023) / 1024)},
+        {"... words that all differ", fill_chunks_mixed, (u32)(((size_t)n_seg * kSegWords / 4 + 1023) / 1024)}};
     for (auto &k : once) {
         for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k.k, dim3(k.grid), dim3(256), 0, 0, out, n_seg);
         hipEventRecord(e0);
