@@ -1028,7 +1028,11 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
     // taking every parts-th group of kExpandWaves segments.  The true output size is only known on the device; the
     // capacity bounds it, and a part with nothing to do costs one 16 KiB tile read.
     ExpandArgs a = a0;
-    const u64 want = 4096; // workgroups: 256 CUs x 7 resident x ~2
+    static const u64 want = [] { // workgroups: 256 CUs x 6 resident x ~2.7 (experiments: WAH_EXPAND_WANT)
+        const char *e = std::getenv("WAH_EXPAND_WANT");
+        const long v = e ? std::atol(e) : 0;
+        return v > 0 ? (u64)v : 4096ull;
+    }();
     const u64 segs_per_tile = a.out_capacity / kSegWords / n_tiles;
     u64 parts = (want + n_tiles - 1) / n_tiles;
     if (parts > segs_per_tile / (2 * kExpandWaves)) parts = segs_per_tile / (2 * kExpandWaves);
