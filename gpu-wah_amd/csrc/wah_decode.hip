@@ -403,7 +403,7 @@ __device__ __forceinline__ void expand_steps(const ExpandArgs &a, const u32 *s_w
     asm volatile("" : "+v"(soff));
     const uint4 fq = reinterpret_cast<const uint4 *>(flag)[lane];
     const u32 f[4] = {fq.x, fq.y, fq.z, fq.w};
-    u32 before4 = (uniform32(first_word) - 1u) * 4u;      // byte offset of (first_word + flags in earlier steps - 1): scalar
+    u32 before = uniform32(first_word) - 1u;              // first_word + flags in earlier steps - 1: scalar
     // four steps at a time: their ranks first, then the four gathers together, then decode and store
 #pragma unroll
     for (int g = 0; g < (int)kSteps / 4; ++g) {
@@ -416,8 +416,8 @@ __device__ __forceinline__ void expand_steps(const ExpandArgs &a, const u32 *s_w
             // running count stays on the scalar unit
             const u64 m1 = m >> 1;
             const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)m1, 0u));
-            r4[q] = (below << 2) + (before4 + (((u32)m & 1u) << 2));
-            before4 += (u32)__builtin_popcountll(m) << 2;
+            r4[q] = (below + (before + ((u32)m & 1u))) << 2; // byte offset of the source word
+            before += (u32)__builtin_popcountll(m);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
