@@ -130,8 +130,12 @@ __global__ void gen_clustered_kernel(u32 *out, u64 n, u64 seed, u64 thr) {
     }
 }
 
+// (the bench's copy ceiling) ONE 16-byte load and store per thread, 4 KiB per workgroup, no loop: the fastest copy of the
+// shapes measured on this chip (tools/copy_shapes_time.hip: 6.2 TB/s read + written; a grid-stride loop of 1024 workgroups,
+// the ceiling of the earlier rounds, 5.3-5.7; four per thread 5.8)
 __global__ __launch_bounds__(256) void copy_kernel(const uint4 *in, uint4 *out, u64 n16) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (u64)gridDim.x * blockDim.x) out[i] = in[i];
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) out[i] = in[i];
 }
 
 } // namespace
@@ -341,7 +345,7 @@ hipError_t launch_gen_clustered(u32 *out, u64 n, u64 seed, u64 thr, hipStream_t 
 hipError_t launch_copy(const u32 *in, u32 *out, u64 n, hipStream_t s) {
     const u64 n16 = n / 4;
     if (n16 == 0) return hipSuccess;
-    hipLaunchKernelGGL(copy_kernel, dim3(1024), dim3(256), 0, s, reinterpret_cast<const uint4 *>(in),
+    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint4 *>(in),
                        reinterpret_cast<uint4 *>(out), n16);
     return hipGetLastError();
 }
