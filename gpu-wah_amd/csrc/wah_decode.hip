@@ -1035,6 +1035,9 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
     }();
     const u64 segs_per_tile = a.out_capacity / kSegWords / n_tiles;
     u64 parts = (want + n_tiles - 1) / n_tiles;
+    // ... and a workgroup should not expand much more than 24 segments (six per wave): the chip writes faster the shorter its
+    // waves live (clustered GiB, 1082 tiles of 250 segments: 4 parts 0.245 ms, 8..14 parts 0.226-0.231, 16 parts 0.249)
+    if (parts < segs_per_tile / 24) parts = segs_per_tile / 24;
     if (parts > segs_per_tile / (2 * kExpandWaves)) parts = segs_per_tile / (2 * kExpandWaves);
     if (parts < 1) parts = 1;
     if (parts > 1024) parts = 1024;
