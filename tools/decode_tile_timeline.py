@@ -34,7 +34,8 @@ for kind in sys.argv[1:] or ["sparse"]:
     keep = (life > 0) & (life < 100_000_000) & (t[:, 1] >= t[:, 0]) & (t[:, 6] >= t[:, 5])
     print(f"({int(keep.sum())} of {n_tiles} rows kept)")
     t = t[keep]
-    start, staged, pub, flags, base, bar3, end, _ = (t[:, i] for i in range(8))
+    start, staged, pub, flags, base, bar3, end, bidx = (t[:, i] for i in range(8))
+    rows = np.nonzero(keep)[0] if False else None
     loop0, setup, seg1, seg2, loop_end, bar4, loop1, nseg = (t[:, i] for i in range(8, 16))
     t0 = start.min()
     us = lambda x: x / 100.0
@@ -56,6 +57,9 @@ for kind in sys.argv[1:] or ["sparse"]:
     print(f"     whole segment loop of the tile                               {q(loop_end - loop0)}")
     print(f"     -> the next tile's segment loop (image, flags, counts)       {q((loop1 - bar4)[loop1 > 0])}")
     print(f"     the next tile's loop -> end                                  {q((end - loop1)[loop1 > 0])}")
+    tick = np.arange(n_tiles)[keep]
+    dd = bidx - tick
+    print(f"   ticket == blockIdx for {100.0 * np.mean(dd == 0):.1f} % of the workgroups; |difference| median {np.median(np.abs(dd)):.0f}, p90 {np.percentile(np.abs(dd), 90):.0f}, max {np.abs(dd).max():.0f}")
     print(f"   life of the workgroup                           {q(end - start)}")
     s = us(start - t0)
     e = us(end - t0)
