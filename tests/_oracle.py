@@ -78,6 +78,15 @@ class Oracle:
     def compress_mt(self, data, threads):
         return self._run_compress(self.lib.wah_oracle_compress_mt, data, int(threads))
 
+    def compress_mt_into(self, data, out, threads):
+        """compress_mt into a caller's buffer (>= max_words(len(data)) + 1 words): no copy of the result -- for the
+        whole-stream comparisons at the BASELINE sizes, where the stream is gigabytes.  Returns a view of `out`."""
+        a = np.ascontiguousarray(data, dtype=np.uint32)
+        assert out.dtype == np.uint32 and out.size >= self.max_words(a.size) + 1
+        src = a if a.size else np.zeros(1, np.uint32)
+        c = int(self.lib.wah_oracle_compress_mt(_ptr(src), a.size, _ptr(out), int(threads)))
+        return out[:c]
+
     def refsim_compress(self, data):
         return self._run_compress(self.lib.wah_refsim_compress, data)
 

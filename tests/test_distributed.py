@@ -102,6 +102,23 @@ def test_bench_main_two_ranks_gloo():
             assert res["config"]["columns"] == 10 and res["config"]["columns_per_gpu"] == 5
 
 
+def test_bench_main_eight_ranks_gloo():
+    """The world size the driver's scaling run ends with: bench.py starts EIGHT ranks itself (gloo, 127.0.0.1, empty steps,
+    WAH_BENCH_REHEARSE=cpu), both workloads; the columns workload at BASELINE configs[4]'s shape: 1024 columns, 128 per
+    rank, one launch of 128 columns per rank and step; ONE JSON line, n_gpus = 8."""
+    for workload in ("columns", "sparse"):
+        p = _run_bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--workload", workload, "--master-port", str(_free_port())],
+                       {"WAH_BENCH_REHEARSE": "cpu", "OMP_NUM_THREADS": "1"}, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        res = json.loads(lines[0])
+        assert res["n_gpus"] == 8 and res["steps"] == 2 and res["warmup"] == 1 and "rehearsal" in res
+        assert res["scaling"] == ("strong" if workload == "columns" else "weak")
+        if workload == "columns":
+            assert res["config"]["columns"] == 1024 and res["config"]["columns_per_gpu"] == 128
+
+
 def test_bench_column_plan_covers_every_column_once():
     import bench
 

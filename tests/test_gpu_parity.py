@@ -152,6 +152,44 @@ def test_decode_stream_ends_around_tile_boundaries(wah, oracle, words_behind):
             assert np.array_equal(back[:n], mixed), (tiles, words_behind, lack, "fill in front")
 
 
+def test_decode_plain_tiles_and_lone_fills(wah, oracle):
+    """decode_tile_kernel takes a short cut for PLAIN tiles -- every word of the tile's 8192 and of the 1152 behind it a literal:
+    group p is word p.  A fill of count 1 (a lone all-zero or all-one group: what compress() writes for it, tests.cpp:146)
+    holds one group like a literal and must not pass for one: streams of literals with single fill words of count 1 at the
+    places that decide -- inside a tile, its first and last word, among the words behind a tile and behind a batch of two, in
+    the tile in front of a plain one -- and foreign fills (count 0, count 2) at the same places, against the oracle's decoder."""
+    rng = np.random.default_rng(11)
+    tiles = 5
+    base = rng.integers(1, 0x7FFFFFFF, tiles * 8192 + 700, dtype=np.int64).astype(np.uint32)  # literals, none of them 0 or 0x7FFFFFFF
+    base[base == 0x7FFFFFFF] = 5
+    spots = [0, 1, 4095, 4096, 8191, 8192, 8193, 8192 + 1151, 8192 + 1152, 2 * 8192 - 1, 2 * 8192, 2 * 8192 + 1151, 2 * 8192 + 1152,
+             3 * 8192 + 17, 4 * 8192 - 1, 4 * 8192 + 600, base.size - 1]
+    for word in (0x80000001, 0xC0000001, 0x80000002, 0xC0000000, 0x80000000):
+        for spot in spots:
+            stream = base.copy()
+            stream[spot] = word
+            want = oracle.decompress(stream)
+            got = _host(wah.decompress_device(_dev(stream), want.size + 1))
+            assert np.array_equal(got[: want.size], want), (hex(word), spot)
+    # ... several at once, and the untouched stream (every tile plain but the last, which the stream's end makes ordinary)
+    stream = base.copy()
+    stream[[5, 8192 + 3, 3 * 8192 - 2, 4 * 8192 + 1]] = [0x80000001, 0xC0000001, 0xC0000001, 0x80000001]
+    for st in (stream, base):
+        want = oracle.decompress(st)
+        assert np.array_equal(_host(wah.decompress_device(_dev(st), want.size + 1))[: want.size], want)
+    # a capacity that cuts the output inside a plain tile: reported, nothing written behind it
+    import torch
+    want = oracle.decompress(base)
+    cap = 992 * 9 + 100
+    out = torch.full((cap + 64,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    dec = wah.DeviceDecompressor(base.size, cap)
+    dec.out = out[:cap]
+    dec.run(_dev(base))
+    with pytest.raises(wah.WahError):
+        dec.status()
+    assert np.array_equal(_host(out[:cap]), want[:cap]) and bool((out[cap:] == 0x5A5A5A5A).all())
+
+
 # ---------------------------------------------------------------- distributions
 def _datasets(oracle, n):
     yield "p0.5", oracle.gen_uniform(n, 1337, 0.5)
@@ -1019,9 +1057,34 @@ def test_capacity_and_workspace_errors(wah, oracle):
 
 
 # ---------------------------------------------------------------- BASELINE full-size configurations
-def _full_size_case(wah, oracle, d_in, n, sample_segments, expect_ratio=None):
-    """Properties that do not need a full CPU pass: prefix equality with the oracle (segments are independent,
-    F4), decoded size, round-trip identity on the device, monotone segment index."""
+def _whole_stream_equals_oracle(oracle, d_in, c, slice_segments=1 << 21):
+    """The ENTIRE compressed stream `c` of the bitmap `d_in` (both on the device) against the oracle on the host's cores
+    ("compressed == CPU oracle"; source.cpp:97-103 compares every word).  The bitmap is taken to the
+    host in slices of whole segments (2 GiB by default; segments are independent, F4 -- the oracle's own threads split
+    it the same way); where a slice's words lie in the stream follows from the ORACLE's counts, not from anything the
+    GPU reported.  Returns the number of words compared (= the oracle's C)."""
+    threads = min(os.cpu_count() or 1, 256)
+    n = d_in.numel()
+    step = 992 * slice_segments
+    out = np.empty(oracle.max_words(min(n, step)) + 1, np.uint32)
+    pos = 0
+    for lo in range(0, max(n, 1), step):
+        part = _host(d_in[lo: lo + step])
+        want = oracle.compress_mt_into(part, out, threads)
+        got = _host(c[pos: pos + len(want)])
+        assert len(got) == len(want), (lo, pos, len(got), len(want))
+        if not np.array_equal(got, want):
+            bad = int(np.flatnonzero(got != want)[0])
+            raise AssertionError(f"compressed word {pos + bad} (slice at input word {lo}): {got[bad]:#x} != oracle {want[bad]:#x}")
+        pos += len(want)
+        del part, got
+    assert pos == c.numel(), (pos, c.numel())
+    return pos
+
+
+def _full_size_case(wah, oracle, d_in, n, expect_ratio=None):
+    """BASELINE sizes: the WHOLE compressed stream == the oracle's (every word; the oracle runs on all host cores), the
+    segment index against the stream, decoded size, round-trip identity on the device."""
     import torch
 
     comp = wah.DeviceCompressor(n, indexed=True)
@@ -1033,17 +1096,13 @@ def _full_size_case(wah, oracle, d_in, n, sample_segments, expect_ratio=None):
     assert bool((offs[1:] > offs[:-1]).all())
     if expect_ratio:
         assert expect_ratio[0] < C / n < expect_ratio[1], C / n
-    # oracle on a prefix of whole segments
-    m = 992 * sample_segments
-    prefix = _host(d_in[:m])
-    want = oracle.compress(prefix)
-    assert int(offs[sample_segments]) == len(want)
-    assert np.array_equal(_host(c[: len(want)]), want)
-    # ... and on the last segments (tail path)
-    tail_seg = (n // 992) - 3
-    tail = _host(d_in[992 * tail_seg:])
-    want_tail = oracle.compress(tail)
-    assert np.array_equal(_host(c[int(offs[tail_seg]):]), want_tail)
+    assert _whole_stream_equals_oracle(oracle, d_in, c) == C
+    # the segment index against the oracle: where a few segments start, the last ones (tail path) among them
+    n_seg = (wah.max_compressed_words(n) + 1023) // 1024
+    for seg in sorted({1, n_seg // 3, n_seg - min(3, n_seg)} & set(range(n_seg))):
+        want = oracle.compress(_host(d_in[992 * seg: (992 * (seg + 2) if seg + 3 < n_seg else n)]))
+        at = int(offs[seg])
+        assert np.array_equal(_host(c[at: at + len(want)]), want), seg
     # round trip on the device
     dec = wah.DeviceDecompressor(C, n + 1)
     dec.run(c)
@@ -1060,30 +1119,30 @@ def _full_size_case(wah, oracle, d_in, n, sample_segments, expect_ratio=None):
 def test_config2_sparse_1gib_round_trip(wah, oracle, n):
     """BASELINE config 2: 1 GiB uniform p=0.01, compress + decompress on one GPU (whole blocks and tail)."""
     d_in = wah.gen_uniform_device(n, 1337, 0.01)
-    _full_size_case(wah, oracle, d_in, n, sample_segments=4096, expect_ratio=(0.47, 0.49))
+    _full_size_case(wah, oracle, d_in, n, expect_ratio=(0.47, 0.49))
 
 
 def test_config3_clustered_1gib(wah, oracle):
     """BASELINE config 3: 1 GiB clustered runs (mean 4096 bits): long-fill stress."""
     n = 268435200
     d_in = wah.gen_clustered_device(n, 1337)
-    _full_size_case(wah, oracle, d_in, n, sample_segments=4096, expect_ratio=(0.012, 0.022))
+    _full_size_case(wah, oracle, d_in, n, expect_ratio=(0.012, 0.022))
 
 
 def test_config4_dense_1gib(wah, oracle):
     """BASELINE config 4: 1 GiB p=0.5: all literals, C = G."""
     n = 268435200
     d_in = wah.gen_uniform_device(n, 1337, 0.5)
-    C = _full_size_case(wah, oracle, d_in, n, sample_segments=2048)
+    C = _full_size_case(wah, oracle, d_in, n)
     assert abs(C - (32 * n + 30) // 31) <= 2
 
 
 def test_beyond_2_31_words(wah, oracle):
     """the reference is limited to dataSize < 2^31 words (int indices).  Here sizes, offsets and word
-    indices are 64-bit: an 8 GiB + bitmap (2^31 + 992 * 5 + 3 words) round-trips, and its prefix matches the oracle."""
+    indices are 64-bit: an 8 GiB + bitmap (2^31 + 992 * 5 + 3 words) round-trips, and its whole stream matches the oracle."""
     n = (1 << 31) + 992 * 5 + 3
     d_in = wah.gen_uniform_device(n, 4242, 0.01)
-    _full_size_case(wah, oracle, d_in, n, sample_segments=2048, expect_ratio=(0.47, 0.49))
+    _full_size_case(wah, oracle, d_in, n, expect_ratio=(0.47, 0.49))
 
 
 def test_config5_columns(wah, oracle):
@@ -1172,9 +1231,11 @@ def test_tile_shapes_of_a_launch(wah, oracle):
 def _check_column_launch(wah, oracle, n_columns, n=33554400, seed=1337):
     """`n_columns` columns of `n` words (the three bench distributions in turn) compressed in ONE launch, exactly as
     bench.py's columns workload does it (column matrix resident in HBM, indexed compressor sized for the whole batch).
-    Checked: the column offsets out of the segment index; for one column of each distribution (the first three and the last
-    three columns) the column's stream == compressing that column alone == the oracle on a 1024-segment prefix; the
-    index decode of those columns == the matrix rows.  Returns the number of words of the launch."""
+    Checked: the WHOLE stream of the launch == the oracle's, every column, every superrow of the scan (the columns are
+    whole segments, so the launch's stream is the oracle's stream of the flat matrix; taken to the host 16 columns at a
+    time); the column offsets out of the segment index == the oracle's column lengths; the index decode of ALL segments
+    and the general decoder over the whole stream == the matrix; a column of each distribution == compressing it alone.
+    Returns the number of words of the launch."""
     import torch
 
     specs = [wah.columns.column_spec(c, n, seed) for c in range(n_columns)]
@@ -1184,21 +1245,31 @@ def _check_column_launch(wah, oracle, n_columns, n=33554400, seed=1337):
     offs = offs.cpu().numpy()
     segs = n // 992
     assert len(offs) == n_columns + 1 and offs[0] == 0 and offs[-1] == stream.numel() == int(comp.count.item())
-    assert bool(np.all(np.diff(offs) >= segs))  # every segment holds at least one word
     every = comp.seg_offsets[: n_columns * segs + 1]
     assert bool((every[1:] > every[:-1]).all())
+    # every word of the launch against the oracle, and the column offsets against the oracle's counts
+    flat = matrix.view(-1)
+    assert _whole_stream_equals_oracle(oracle, flat, stream, slice_segments=16 * segs) == stream.numel()
+    threads = min(os.cpu_count() or 1, 256)
+    buf = np.empty(oracle.max_words(n) + 1, np.uint32)
+    for c in sorted(set(list(range(min(3, n_columns))) + [n_columns // 2] + list(range(max(n_columns - 3, 0), n_columns)))):
+        assert offs[c + 1] - offs[c] == len(oracle.compress_mt_into(_host(matrix[c]), buf, threads)), c
+    # a column of each distribution == compressing that column alone
     one = wah.DeviceCompressor(n)
-    prefix = 992 * 1024
-    for c in sorted(set(list(range(min(3, n_columns))) + list(range(max(n_columns - 3, 0), n_columns)))):
+    for c in range(min(3, n_columns)):
         one.run(matrix[c])
-        alone = one.result()
-        mine = stream[offs[c]: offs[c + 1]]
-        assert bool(torch.equal(alone, mine)), c
-        want = oracle.compress(_host(matrix[c][:prefix]))
-        assert np.array_equal(_host(mine[: len(want)]), want), c
-        back = wah.decompress_segments_device(stream, comp.seg_offsets, matrix.numel(), first_segment=c * segs, n_segments=segs)
-        assert bool(torch.equal(back, matrix[c])), c
-        del back, alone
+        assert bool(torch.equal(one.result(), stream[offs[c]: offs[c + 1]])), c
+    del one
+    # the index decode of every segment of the launch, 16 columns at a time, == the matrix
+    for c0 in range(0, n_columns, 16):
+        c1 = min(c0 + 16, n_columns)
+        back = wah.decompress_segments_device(stream, comp.seg_offsets, matrix.numel(), first_segment=c0 * segs, n_segments=(c1 - c0) * segs)
+        assert bool(torch.equal(back, matrix[c0:c1].reshape(-1))), c0
+        del back
+    # ... and the general decoder (no index) over the whole stream
+    back = wah.decompress_device(stream, matrix.numel() + 1)
+    assert bool(torch.equal(back[: matrix.numel()], flat))
+    del back
     return matrix.numel()
 
 
