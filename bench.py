@@ -490,11 +490,11 @@ def run_rank(args):
         algo_d = 4.0 * c_words + 4.0 * ((31 * groups + 31) // 32)  # decompress: read C, write N'
         achieved = algo_c / (comp_avg * 1e-3) / 1e9
         achieved_d = algo_d / (dec_avg * 1e-3) / 1e9
-        # the general decoder's route (wah_api.hip: decode_common): one pass over the stream when the output is at most eight
-        # times the stream, sums + expand for highly compressed streams (few tiles that expand a lot each)
-        one_pass = (n + 1) // 8 <= c_words and os.environ.get("WAH_DECODE_TWO_PASS") != "1" and os.environ.get("WAH_FORCE_FALLBACK") != "1"
-        decode_kernels = ("decode_tile_kernel (+ decode_expand_list_kernel: the tiles it defers, normally none)" if one_pass
-                          else "decode_sums_kernel + decode_expand_kernel")
+        # the general decoder's route, as the LIBRARY reports it for the timed calls (wah_last_decode_route)
+        decode_kernels = {"one pass": "decode_tile_kernel + decode_expand_list_kernel (the tiles it puts on its list: a highly "
+                                      "compressed stream's all, an incompressible one's none)",
+                          "two launches": "decode_sums_kernel + decode_expand_kernel",
+                          "no wait": "decode_sums_kernel<no wait> + sums_offsets_kernel + decode_expand_kernel"}.get(dec.route, dec.route)
         tr = load_traffic(args.workload) or {}
         out = {
             "metric": "compress+decompress GB/s (input bits), 1 GiB bitmap",

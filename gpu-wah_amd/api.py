@@ -62,6 +62,7 @@ ABI_SYMBOLS = {
     "wah_gen_uniform_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_gen_clustered_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_copy_device": (_int, [_vp, _vp, _u64, _vp]),
+    "wah_last_decode_route": (_int, []),
     "wah_last_error": (ctypes.c_char_p, []),
     "wah_version": (ctypes.c_char_p, []),
 }
@@ -268,10 +269,16 @@ class DeviceCompressor:
 class DeviceDecompressor:
     """Reusable workspace + output for decoding streams of up to `c_words` words into `out_capacity` words."""
 
-    def __init__(self, c_words, out_capacity_words, device="cuda:0", no_wait=False):
-        """no_wait: the sums pass by the route in which no workgroup waits for another (include/wah.h: WAH_NO_WAIT)."""
+    ROUTES = {0: "none", 1: "one pass", 2: "two launches", 3: "no wait"}
+
+    def __init__(self, c_words, out_capacity_words, device="cuda:0", no_wait=False, two_launches=False):
+        """no_wait: the sums pass by the route in which no workgroup waits for another (include/wah.h: WAH_NO_WAIT);
+        two_launches: scan and expansion as two launches (WAH_TWO_LAUNCHES).  After run(): `route` = the decoder the
+        library launched (wah_last_decode_route)."""
         torch = _torch()
         self.no_wait = bool(no_wait)
+        self.two_launches = bool(two_launches)
+        self.route = "none"
         self.c_words = int(c_words)
         self.capacity = int(out_capacity_words)
         self.ws_bytes = int(lib().wah_decompress_workspace_bytes(self.c_words, self.capacity))
@@ -287,8 +294,9 @@ class DeviceDecompressor:
         if c > self.c_words or c > d_comp.numel():
             raise WahError("stream larger than this decompressor was sized for")
         rc = lib().wah_decompress_device_ex(d_comp.data_ptr(), c, self.out.data_ptr(), self.capacity, self.info.data_ptr(),
-                                            2 if self.no_wait else 0, self.workspace.data_ptr(), self.ws_bytes,
-                                            _stream_ptr(torch, stream))
+                                            (2 if self.no_wait else 0) | (4 if self.two_launches else 0),
+                                            self.workspace.data_ptr(), self.ws_bytes, _stream_ptr(torch, stream))
+        self.route = self.ROUTES.get(int(lib().wah_last_decode_route()), "?")
         _check(rc, "wah_decompress_device")
 
     def status(self, stream=None):

@@ -305,12 +305,15 @@ void *host_result_alloc(size_t bytes, bool *huge) {
     return std::malloc(bytes ? bytes : sizeof(uint32_t));
 }
 
-// WAH_TEST_TIMEOUT=1 (tests only, read per call): the host-pointer entry points treat their first launch as if one of
-// its bounded waits had expired, which sends them down the no-wait route.
+// WAH_FAULT_INJECT=timeout (include/wah.h; read per call): the host-pointer entry points treat their first launch as if one
+// of its bounded waits had expired, which sends them down the no-wait route -- the only way to see that route taken by
+// itself on a healthy GPU.
 bool test_timeout_hook() {
-    const char *e = std::getenv("WAH_TEST_TIMEOUT");
-    return e && e[0] == '1';
+    const char *e = std::getenv("WAH_FAULT_INJECT");
+    return e && std::strcmp(e, "timeout") == 0;
 }
+
+thread_local int g_last_route = wah::kRouteNone; // which decoder the calling thread's last decode call launched
 
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
@@ -497,7 +500,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
 #ifdef WAH_DIAG
     {
         static const uint32_t tune = [] { // diagnostic build only: 77 / 78 = per-tile time line (tools/tile_timeline.py)
-            const char *e = std::getenv("WAH_TUNE");
+            const char *e = wah::experiment_env("WAH_TUNE");
             return e ? (uint32_t)std::strtoul(e, nullptr, 0) : 0u;
         }();
         a.tune = tune;
@@ -565,8 +568,10 @@ int wah_decompress_status(void *d_workspace, void *stream) { return read_status(
 // front of the launch, which makes it a fresh workspace every time.
 static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                          uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream, bool do_scan,
-                         bool do_expand, bool clear_first = false, uint64_t *host_result = nullptr, bool no_wait = false) {
+                         bool do_expand, bool clear_first = false, uint64_t *host_result = nullptr, bool no_wait = false,
+                         bool two_launches = false) {
     g_err[0] = 0;
+    g_last_route = wah::kRouteNone;
     // WAH_FORCE_FALLBACK=1: every sums pass takes the no-wait route (tests; a GPU shared in ways that starve the scan
     // route's waits).  Read per call: it is a switch for a running process too.
     if (!no_wait && do_scan) {
@@ -593,16 +598,18 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
     hipStream_t s = static_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(d_workspace);
     hipError_t e = hipSuccess;
-    // ONE pass over the stream (decode_tile_kernel) when the scan and the expansion are asked for together, the stream is
-    // 16-byte aligned and the output is at most eight times the stream (a highly compressed stream has few tiles that expand
-    // a lot each: decode_expand_kernel shares such a tile out over many workgroups, and its second read of the stream costs
-    // next to nothing).  WAH_DECODE_TWO_PASS=1: never (experiments, tests of the two-pass route).
+    // ONE pass over the stream (decode_tile_kernel) whenever the scan and the expansion are asked for together and the stream is
+    // 16-byte aligned -- whatever the stream and whatever the capacity: the kernel decides TILE BY TILE, from the tile's own
+    // words, whether it expands the tile itself (up to about 7 groups per word) or puts it on the list of tiles that the
+    // launch behind it shares out over work items of 32 segments (a highly compressed stream: every tile; a long fill inside
+    // incompressible data: that tile).  WAH_TWO_LAUNCHES (flags) / WAH_DECODE_TWO_PASS=1 (experiment builds): the scan and
+    // the expansion as two launches.
     static const bool two_pass_only = [] {
-        const char *f = std::getenv("WAH_DECODE_TWO_PASS");
+        const char *f = wah::experiment_env("WAH_DECODE_TWO_PASS");
         return f && f[0] == '1';
     }();
-    const bool one_pass = do_scan && do_expand && !no_wait && !two_pass_only && c_words != 0 && aligned16(d_comp) &&
-                          out_capacity_words / 8 <= c_words;
+    const bool one_pass = do_scan && do_expand && !no_wait && !two_launches && !two_pass_only && c_words != 0 && aligned16(d_comp);
+    if (do_expand || do_scan) g_last_route = one_pass ? wah::kRouteOnePass : no_wait ? wah::kRouteNoWait : wah::kRouteTwoLaunches;
     if (one_pass) {
         if (clear_first) e = wah::launch_clear(ws, l.base_off, s); // (control block -- with the deferred tiles' counters -- and scan area)
         if (e != hipSuccess) {
@@ -706,14 +713,16 @@ int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_
 
 int wah_decompress_device_ex(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                              uint64_t *d_out_info, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream) {
-    if (flags & ~(unsigned)WAH_NO_WAIT) {
+    if (flags & ~(unsigned)(WAH_NO_WAIT | WAH_TWO_LAUNCHES)) {
         g_err[0] = 0;
         set_err("unknown flag");
         return WAH_ERR_ARG;
     }
     return decode_common(d_comp, c_words, d_out, out_capacity_words, d_out_info, d_workspace, workspace_bytes, stream,
-                         true, true, false, nullptr, (flags & WAH_NO_WAIT) != 0);
+                         true, true, false, nullptr, (flags & WAH_NO_WAIT) != 0, (flags & WAH_TWO_LAUNCHES) != 0);
 }
+
+int wah_last_decode_route(void) { return g_last_route; }
 
 int wah_decompress_scan_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_out_info, void *d_workspace,
                                size_t workspace_bytes, void *stream) {
@@ -1131,12 +1140,17 @@ uint32_t *wah_compress(const uint32_t *data_host, uint64_t n_words, uint64_t *ou
     // phase 1: allocate + H2D (compress.cu:57-120)
     hc.start();
     const uint64_t cap = wah_max_compressed_words(n_words);
-    const size_t ws_bytes = wah_compress_workspace_bytes(n_words);
     void *d_in = nullptr, *d_out = nullptr, *d_ws = nullptr;
-    if (!hc.alloc(0, &d_in, n_words * sizeof(uint32_t), "space for the data")) return nullptr;
+    // (one word more than the data: the buffer is decompress()'s output buffer next, and a bitmap whose length is not a
+    //  multiple of 31 decodes to one padding word more, decompress.cu:84-93)
+    if (!hc.alloc(0, &d_in, (n_words + 1) * sizeof(uint32_t), "space for the data")) return nullptr;
     if (!hc.alloc(1, &d_out, cap * sizeof(uint32_t), "space for the compressed output")) return nullptr;
     bool fresh_ws = false;
-    if (!hc.alloc(2, &d_ws, ws_bytes, "workspace", &fresh_ws)) return nullptr;
+    if (!hc.alloc(2, &d_ws, wah_compress_workspace_bytes(n_words), "workspace", &fresh_ws)) return nullptr;
+    // a kept workspace is named with ITS size, call after call, whatever this call needs of it: where a launch keeps its
+    // entries follows from the size it is given (include/wah.h), and entries that moved with the input's size would let
+    // one call's tables be read as another call's published entries
+    const size_t ws_bytes = hc.cache.cap[2];
     // the compress workspace is zeroed once; from then on the kernel keeps it up itself (launch epochs)
     if (fresh_ws && wah_workspace_init_device(d_ws, ws_bytes, nullptr) != WAH_OK) return nullptr;
     uint64_t *d_cnt = reinterpret_cast<uint64_t *>(static_cast<uint32_t *>(d_ws) + wah::kCtlResult); // beside the error word
@@ -1215,10 +1229,10 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     // phase 1: allocate + H2D (decompress.cu:34-54)
     hc.start();
     void *d_comp = nullptr, *d_ws0 = nullptr;
-    const size_t ws0 = wah_decompress_workspace_bytes(c_words, 0);
     if (!hc.alloc(1, &d_comp, c_words * sizeof(uint32_t), "space for the compressed data")) return nullptr;
     bool fresh_ws = false;
-    if (!hc.alloc(4, &d_ws0, ws0, "scan workspace", &fresh_ws)) return nullptr;
+    if (!hc.alloc(4, &d_ws0, wah_decompress_workspace_bytes(c_words, 0), "scan workspace", &fresh_ws)) return nullptr;
+    const size_t ws0 = hc.cache.cap[4]; // (named with its own size every time: see wah_compress)
     // zeroed once; from then on the sums kernel keeps it up itself (launch epochs)
     if (fresh_ws && wah_workspace_init_device(d_ws0, ws0, nullptr) != WAH_OK) return nullptr;
     uint64_t *d_info = reinterpret_cast<uint64_t *>(static_cast<uint32_t *>(d_ws0) + wah::kCtlResult); // beside the error word

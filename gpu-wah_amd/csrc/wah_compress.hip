@@ -17,6 +17,7 @@
 //   * output offsets come from a one-hop "row scan" over 4-byte {epoch, count} granules written and read with
 //     agent-scope accesses (correct across the 8 non-coherent XCD L2s), instead of thrust::exclusive_scan + moveData
 //     (compress.cu:133-166, kernels.cu:273-280); nothing is persistent and nothing is cleared between launches.
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1271,7 +1272,7 @@ hipError_t launch_bitop_tiles(const CompressArgs &a, const BitopOperands &ops, h
 // segments per wavefront for a bitmap of n_segments: enough tiles to occupy the chip first, long tiles after that
 uint32_t compress_wave_segs(uint64_t n_segments) {
     static const int forced = [] { // experiments only
-        const char *e = std::getenv("WAH_WAVE_SEGS");
+        const char *e = experiment_env("WAH_WAVE_SEGS");
         return e ? std::atoi(e) : 0;
     }();
     if (forced == 1 || forced == 2 || forced == 4 || forced == kCompressMaxWaveSegs) return (uint32_t)forced;
@@ -1289,20 +1290,26 @@ uint32_t compress_wave_segs(uint64_t n_segments) {
 // round: one shape, the smallest that fits them into one round.
 TileShape compress_tile_shape(uint64_t n_segments) {
     static const int forced = [] { // experiments only: 0 switches the kernel off, 1..3: one shape
-        const char *e = std::getenv("WAH_WAVE_PAIRS");
+        const char *e = experiment_env("WAH_WAVE_PAIRS");
         return e ? std::atoi(e) : -1;
     }();
-    static const uint64_t slots = [] {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        return (uint64_t)cus * 2u;
-    }();
+    // (per device: a process may drive several, and not all of them need be the same part)
+    static std::atomic<uint32_t> slots_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    uint32_t known = slots_of[dev].load(std::memory_order_relaxed);
+    if (known == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        known = (uint32_t)cus * 2u;
+        slots_of[dev].store(known, std::memory_order_relaxed);
+    }
+    const uint64_t slots = known;
     const uint64_t pairs = (n_segments + 1) / 2;
     const uint64_t w = (uint64_t)kTileWaves;
     TileShape t = {3, 3, 0, 0};
     if (forced == 0) return TileShape{0, 0, 0, 0};
-    static const char *shape_env = std::getenv("WAH_SHAPE"); // experiments only: "big_tiles,tail_pairs" (body tiles of 3 pairs)
+    static const char *shape_env = experiment_env("WAH_SHAPE"); // experiments only: "big_tiles,tail_pairs" (body tiles of 3 pairs)
     if (shape_env) {
         unsigned long big = 0, tail = 0;
         if (std::sscanf(shape_env, "%lu,%lu", &big, &tail) == 2 && tail >= 1 && tail <= 2 && big * w * 3 <= pairs) {

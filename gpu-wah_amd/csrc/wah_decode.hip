@@ -199,26 +199,30 @@ __device__ __forceinline__ u64 sums_resolve(u32 *ctrl, u32 *gen_desc, u32 wt, u3
 // every workgroup of the launch has read which counters are the launch's: the other ones are zeroed for the next launch
 // (nobody reads them any more), these are handed to whoever walks the list.
 __device__ __forceinline__ void defer_counters_next(u32 *c) {
-    const u32 seq = __hip_atomic_load(c + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(c + ((seq + 1u) & 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(c + 3u + ((seq + 1u) & 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(c + 2, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 seq = __hip_atomic_load(c + kDeferSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<u64 *>(c) + ((seq + 1u) & 1u), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(c + kDeferSeq, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the counter pair {entries:32, parts:32} a launch that may append counts in (read by every workgroup at its start)
+__device__ __forceinline__ u64 *defer_counters_mine(u32 *c) {
+    return reinterpret_cast<u64 *>(c) + (uniform32(__hip_atomic_load(c + kDeferSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u);
 }
 
 // One expand tile onto the list of tiles that are decoded by workgroups of their own (the one-pass decoder's second launch,
 // the launch behind decode_expand_kernel).  An entry = {tile, parts} {sum of the parts of the entries before it}: the tile's
-// output segments are shared out over `parts` workgroups of that launch, one per 64 segments (a long fill inside otherwise
-// incompressible data: millions of groups out of one word), workgroup (sum + p) mod G taking part p -- so the list holds
-// ONE entry per tile whatever the size of the output, and the launch's workgroups get equal shares whatever the mix of
-// tiles.  c = the launch's counters (kCtlDefer + (launch & 1)).  false: the list is full (the tile is not on it).
-__device__ __forceinline__ bool dt_defer(u32 *c, u64 *list, u32 capacity, u64 tile, u64 groups) {
+// output segments are shared out over `parts` WORK ITEMS of that launch, kDeferPartSegs segments each (a long fill inside
+// otherwise incompressible data: millions of groups out of one word; a highly compressed stream: every tile) -- so the list
+// holds ONE entry per tile whatever the size of the output.  Slot and sum come out of ONE 64-bit atomic, so the entries
+// are SORTED by their sums: work item k of the launch finds its entry by search (expand_list).  c = the launch's counter
+// pair (defer_counters_mine).  false: the list is full (the tile is not on it).
+__device__ __forceinline__ bool dt_defer(u64 *c, u64 *list, u32 capacity, u64 tile, u64 groups) {
     const u64 segs = groups / kSegGroups + 2ull;
-    const u32 parts = segs >= 64ull * 4096ull ? 4096u : (u32)((segs + 63ull) / 64ull);
-    const u32 slot = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 parts = segs >= (u64)kDeferPartSegs * 65536ull ? 65536u : (u32)((segs + kDeferPartSegs - 1ull) / kDeferPartSegs);
+    const u64 old = __hip_atomic_fetch_add(c, 1ull | ((u64)parts << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const u32 slot = (u32)old;
     if (slot >= capacity) return false; // (also: a counter that did not start at zero must not lead outside the list)
-    const u32 before = __hip_atomic_fetch_add(c + 3, parts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     list[2ull * slot] = tile | ((u64)parts << 32);
-    list[2ull * slot + 1] = before;
+    list[2ull * slot + 1] = old >> 32;
     return true;
 }
 
@@ -329,8 +333,7 @@ __global__ __launch_bounds__(kSumWaves * 64) void decode_sums_kernel(const ScanA
     if (lane < kSumWaves * kWaveTiles && et0 + lane < n_tiles) {
         bool listed = false;
         if (a.defer_list && part / kSegGroups > kListSegs) {
-            u32 *const count = a.ctrl + kCtlDefer + (__hip_atomic_load(a.ctrl + kCtlDefer + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u);
-            listed = dt_defer(count, a.defer_list, a.defer_capacity, et0 + lane, part);
+            listed = dt_defer(defer_counters_mine(a.ctrl + kCtlDefer), a.defer_list, a.defer_capacity, et0 + lane, part);
         }
         a.tile_flags[et0 + lane] = (uint8_t)(s_empty[lane] | (listed ? 2u : 0u));
     }
@@ -773,35 +776,38 @@ __device__ __forceinline__ void expand_list(const ExpandArgs &a, const u64 *list
     // a workspace that the launch before refused (WAH_ERR_WORKSPACE: neither zeroed nor left by a launch) holds no list
     if (__hip_atomic_load(a.ctrl + kCtlError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kErrWorkspace) return;
     const u64 n_et = (a.c_words + kScanTileWords - 1) / kScanTileWords;
-    // the counter of the launch that has just ended (count[2] = launches so far; wah_internal.hpp, kCtlDefer): read only --
-    // the NEXT launch that may append zeroes it
-    const u32 seq = uniform32(__hip_atomic_load(count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    u32 n = uniform32(__hip_atomic_load(count + ((seq - 1u) & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    // the counter pair of the launch that has just ended (count[kDeferSeq] = launches so far; wah_internal.hpp, kCtlDefer): read
+    // only -- the NEXT launch that may append zeroes it
+    const u32 seq = uniform32(__hip_atomic_load(count + kDeferSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const u64 pair = __hip_atomic_load(reinterpret_cast<const u64 *>(count) + ((seq - 1u) & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u32 n = uniform32((u32)pair);
+    const u32 items = uniform32((u32)(pair >> 32)); // work items = the sum of the entries' parts
     if (n > capacity) n = capacity; // (whatever the counter holds: every access stays inside the list and the stream)
-    // 64 entries at a time, one per lane: which of them have a part for this workgroup at all (most have none: an entry of
-    // few parts concerns few workgroups, and one whose tile `parts` spreads well enough concerns nobody)
     const u32 lane = lane_id();
-    for (u32 i0 = 0; i0 < n; i0 += 64u) {
-        const u32 i = i0 + lane;
-        u64 e = 0, before = 0;
-        if (i < n) {
-            e = list[2ull * i];
-            before = list[2ull * i + 1];
+    // Work item k (k = w, w + G, ...) belongs to the LAST entry whose sum of earlier parts is <= k: the entries are sorted by
+    // that sum (dt_defer), so a 64-ary search finds it in two or three rounds of one load each -- every wave for itself, no
+    // barrier (the values are the same in all of them).
+    for (u32 k = w; k < items; k += G) {
+        u32 lo = 0, len = n; // the entry lies in [lo, lo + len)
+        while (len > 64u) {
+            const u32 stride = (len + 63u) / 64u;
+            const u32 i = lo + lane * stride;
+            const bool le = lane * stride < len && (u32)list[2ull * i + 1] <= k;
+            const u32 below = (u32)__popcll(__ballot(le)); // (lane 0's entry is always <= k: the one found in the round before)
+            const u32 at = (below ? below - 1u : 0u) * stride;
+            lo += at;
+            len = len - at < stride ? len - at : stride;
         }
-        const u32 tile_l = (u32)e, parts_l = (u32)(e >> 32);
-        const u32 first_l = (w + G - (u32)(before % G)) % G; // my first part of the entry (if it has that many)
-        bool mine = i < n && tile_l < n_et && parts_l != 0u && parts_l <= 4096u && first_l < parts_l;
-        if (mine && listed_tile_is_regular(a, tile_l, regular_parts)) mine = false;
-        u64 m = __ballot(mine);
-        while (m) {
-            const int l = __builtin_ctzll(m);
-            m &= m - 1;
-            const u32 tile = (u32)__builtin_amdgcn_readlane((int)tile_l, l), parts = (u32)__builtin_amdgcn_readlane((int)parts_l, l);
-            for (u32 p = (u32)__builtin_amdgcn_readlane((int)first_l, l); p < parts; p += G) {
-                expand_tile(a, tile, p, parts);
-                __syncthreads(); // the LDS image goes to the next tile
-            }
-        }
+        const bool le = lane < len && (u32)list[2ull * (lo + lane) + 1] <= k;
+        const u32 below = (u32)__popcll(__ballot(le));
+        if (below == 0u) continue; // (a list that is not what dt_defer wrote)
+        const u32 e = uniform32(lo + below - 1u);
+        const u64 entry = list[2ull * e];
+        const u32 tile = uniform32((u32)entry), parts = uniform32((u32)(entry >> 32)), part = k - uniform32((u32)list[2ull * e + 1]);
+        if (tile >= n_et || parts == 0u || parts > 65536u || part >= parts) continue;
+        if (listed_tile_is_regular(a, tile, regular_parts)) continue;
+        if (k != w) __syncthreads(); // the LDS image goes to the next tile
+        expand_tile(a, tile, part, parts);
     }
 }
 
@@ -1000,6 +1006,17 @@ __global__ __launch_bounds__(1024) void sums_offsets_kernel(const ScanArgs a) {
     }
 }
 
+// workgroups of the launch that walks the list of deferred / shared-out tiles: one per work item the output can hold (an item =
+// kDeferPartSegs segments), within bounds -- an empty list costs the launch of this many workgroups that read one counter
+// (a stream of compress() holds at most one segment per word: its items are bounded by its length too -- what keeps the launch
+// small for a small stream decoded into a large kept buffer; a foreign stream of few words and giant fills loops)
+static unsigned defer_list_grid(u64 out_capacity, u64 c_words) {
+    const u64 by_capacity = out_capacity / kSegWords / kDeferPartSegs;
+    const u64 by_stream = c_words / kDeferPartSegs + 2u * (c_words / kScanTileWords + 1u);
+    const u64 want = (by_capacity < by_stream ? by_capacity : by_stream) + 64u;
+    return (unsigned)(want < 256u ? 256u : want > 32768u ? 32768u : want);
+}
+
 hipError_t launch_decode_sums(const ScanArgs &a, hipStream_t s) {
     if (a.no_wait) {
         const u64 wg_tiles = (a.n_tiles + kSumWaves - 1) / kSumWaves;
@@ -1029,7 +1046,7 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
     // capacity bounds it, and a part with nothing to do costs one 16 KiB tile read.
     ExpandArgs a = a0;
     static const u64 want = [] { // workgroups: 256 CUs x 6 resident x ~2.7 (experiments: WAH_EXPAND_WANT)
-        const char *e = std::getenv("WAH_EXPAND_WANT");
+        const char *e = experiment_env("WAH_EXPAND_WANT");
         const long v = e ? std::atol(e) : 0;
         return v > 0 ? (u64)v : 4096ull;
     }();
@@ -1049,7 +1066,7 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
     if (a.defer_list && a.out_capacity / kSegWords > 256ull * parts) {
         ExpandArgs x = a;
         x.parts = 1;
-        hipLaunchKernelGGL(decode_expand_list_kernel, dim3(512), dim3(kExpandThreads), 0, s, x, a.defer_list, a.defer_count, a.defer_capacity, a.parts);
+        hipLaunchKernelGGL(decode_expand_list_kernel, dim3(defer_list_grid(a.out_capacity, a.c_words)), dim3(kExpandThreads), 0, s, x, a.defer_list, a.defer_count, a.defer_capacity, a.parts);
     }
     return hipGetLastError();
 }
@@ -1057,7 +1074,7 @@ hipError_t launch_decode_expand(const ExpandArgs &a0, u64 n_tiles, hipStream_t s
 // the general decoder in one pass (decode_tile_kernel) + the launch that takes what it deferred
 hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *defer, hipStream_t s) {
     static const u32 batch = [] { // tiles per workgroup: 2 (experiments: WAH_DT_BATCH=1)
-        const char *e = std::getenv("WAH_DT_BATCH");
+        const char *e = experiment_env("WAH_DT_BATCH");
         return e && e[0] == '1' ? 1u : 2u;
     }();
     TileDecodeArgs t;
@@ -1083,7 +1100,7 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *de
     ExpandArgs x = xa;
     x.parts = 1;
     x.defer_list = nullptr; // (the list is this launch's own argument)
-    hipLaunchKernelGGL(decode_expand_list_kernel, dim3(512), dim3(kExpandThreads), 0, s, x, (const u64 *)t.defer_list, (const u32 *)t.defer_count, t.defer_capacity, 0u);
+    hipLaunchKernelGGL(decode_expand_list_kernel, dim3(defer_list_grid(xa.out_capacity, xa.c_words)), dim3(kExpandThreads), 0, s, x, (const u64 *)t.defer_list, (const u32 *)t.defer_count, t.defer_capacity, 0u);
     return hipGetLastError();
 }
 

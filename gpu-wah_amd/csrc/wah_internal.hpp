@@ -6,7 +6,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 namespace wah {
+
+// Experiment switches (tile shapes, batch sizes, forced routes: what tools/*.sh sweep) are read from the environment only
+// by builds made with -DWAH_EXPERIMENTS (`make -C gpu-wah_amd exp` -> libwah_hip_exp.so, used through WAH_LIB_PATH); the
+// shipped library reads none of them.  (What it does read is documented in include/wah.h: WAH_HOST_CACHE,
+// WAH_FORCE_FALLBACK, WAH_FAULT_INJECT.)
+inline const char *experiment_env(const char *name) {
+#ifdef WAH_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // ---- wire format (reference const.h:3-16) ---------------------------------
 constexpr uint32_t kOnes31 = 0x7FFFFFFFu;    // ONES31
@@ -31,13 +46,16 @@ constexpr uint32_t kCtlClearDone = 96;   // tile kernels: == kCtlWraps + 1 once 
 constexpr uint32_t kCtlError = 160;      // sticky error bits
 constexpr uint32_t kCtlResult = 162;     // host-pointer entry points: two 64-bit results of the launch live here, beside the
                                          // error word, so that ONE 32-byte copy brings status and sizes to the host
-constexpr uint32_t kCtlDefer = 192;      // the decoders' list of tiles that are decoded by workgroups of their own: [0], [1] two counters of
-                                         // entries used in turn, [2] the number of launches that could append so far (launch s counts in
-                                         // [s & 1]; its last tile zeroes the other counters -- nobody reads them any more -- and stores
-                                         // s + 1: whoever walks the list needs no atomics to hand the counters back), [3], [4] the sum of
-                                         // the entries' parts, in turn like [0], [1].  HERE, not beside the list: where the list lies depends
-                                         // on the size of the workspace a call names, and a counter at a place that moves would be found
-                                         // holding an earlier call's data
+constexpr uint32_t kCtlDefer = 192;      // the decoders' list of tiles that are decoded by workgroups of their own: two 64-bit counter pairs
+                                         // {entries:32, sum of their parts:32} at words [0..1] and [2..3], used in turn, and at word
+                                         // [kDeferSeq] the number of launches that could append so far (launch s counts in pair s & 1; its
+                                         // last tile zeroes the other pair -- nobody reads it any more -- and stores s + 1: whoever walks
+                                         // the list needs no atomics to hand the counters back).  HERE, not beside the list: where the list
+                                         // lies depends on the size of the workspace a call names, and a counter at a place that moves
+                                         // would be found holding an earlier call's data
+constexpr uint32_t kDeferSeq = 4;
+constexpr uint32_t kDeferPartSegs = 32;  // output segments per work item of the list's launch (eight per wave: the chip writes faster the
+                                         // shorter its waves live, tools/expand_want_sweep.sh)
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
 constexpr uint32_t kErrTimeout = 1u;     // a bounded wait expired
 constexpr uint32_t kErrCapacity = 2u;    // output would exceed its capacity
@@ -199,6 +217,8 @@ hipError_t launch_bitop_check(const uint64_t *info_a, const uint64_t *info_b, co
 hipError_t launch_decode_sums(const ScanArgs &a, hipStream_t s);
 hipError_t launch_decode_expand(const ExpandArgs &a, uint64_t n_tiles, hipStream_t s);
 hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, uint64_t *defer, hipStream_t s); // one pass: decode_tile_kernel
+// which decoder a call ran (wah_last_decode_route)
+constexpr int kRouteNone = 0, kRouteOnePass = 1, kRouteTwoLaunches = 2, kRouteNoWait = 3;
 constexpr uint32_t kDecodeTileWords = 2 * kScanTileWords; // ... whose workgroup tiles are this long
 hipError_t launch_clear(void *p, size_t bytes, hipStream_t s);
 hipError_t launch_build_index(const uint32_t *comp, uint64_t c_words, const uint64_t *tile_base, const uint64_t *info, uint64_t *offsets,

@@ -74,7 +74,18 @@ void wah_free(void *p);
 /* The two entry points above keep their device buffers between calls (grow-only, one set per device; calls
  * from several threads take turns), where the reference allocates and frees inside every call
  * (compress.cu:57-114,177-202; decompress.cu:34-54,124-131).  This returns them to the device now; setting
- * WAH_HOST_CACHE=0 in the environment restores allocate-and-free per call. */
+ * WAH_HOST_CACHE=0 in the environment restores allocate-and-free per call.
+ * decompress() does not know the decoded size before it has scanned the stream (nor does the reference,
+ * decompress.cu:72-97).  With a kept buffer that is large enough -- the one a compress() or decompress() of this
+ * process left behind: the reference's callers run them in turn on one size, source.cpp:70-103 -- it decodes into it in
+ * ONE pass, one host round trip; without one (a process's first call, a larger bitmap than any before) it scans the
+ * stream, reads the size back, allocates and expands: two passes over the stream, two round trips.
+ *
+ * Environment read by the library (nothing else is; the experiment switches of tools/ exist only in builds made with
+ * -DWAH_EXPERIMENTS): WAH_HOST_CACHE=0 (above); WAH_FORCE_FALLBACK=1 (every launch by its no-wait route, below);
+ * WAH_FAULT_INJECT=timeout -- fault injection: compress() / decompress() treat their first launch as if a bounded
+ * in-kernel wait had expired and take the no-wait route by themselves, as they would on a GPU shared in a way that
+ * starves the waits (the reference has no failure handling to compare with, compress.cu:89-114). */
 void wah_host_cache_release(void);
 
 /* ------------------------------------------------------------------------- *
@@ -153,10 +164,16 @@ int wah_compress_status(void *d_workspace, void *stream);
 /* d_comp: c_words compressed words, 16-byte aligned.  d_out: room for
  * out_capacity_words decoded words.  d_out_info: two device uint64:
  * [0] = ceil(31*G/32) decoded words, [1] = G groups.
- * A stream whose output (out_capacity_words) is at most eight times its size is decoded in ONE pass over it; a more
- * highly compressed one by a scan of the stream + an expansion pass (as _scan_device + _expand_device).  If the decoded
- * words do not fit out_capacity_words: WAH_ERR_CAPACITY from wah_decompress_status(), and d_out holds at most the part
- * that fits (the one-pass route writes as it goes, the other one nothing). */
+ * ONE pass over the stream, whatever the stream and whatever the capacity: the decoder decides tile by tile (8192
+ * words), from the tile's own words, whether the workgroup that holds it expands it (up to about 7 groups per word) or
+ * puts it on a list that a second launch shares out in work items of 32 output segments (a highly compressed stream:
+ * every tile; a long fill inside incompressible data: that tile).  The capacity does not choose the route.  (A stream
+ * that is only 4-byte aligned, and WAH_TWO_LAUNCHES / WAH_NO_WAIT below: a scan of the stream + an expansion pass, as
+ * _scan_device + _expand_device.)  wah_last_decode_route() says which one the calling thread's last call launched.
+ * On ANY status other than WAH_OK the content of d_out is undefined: on WAH_ERR_CAPACITY the one-pass decoder has
+ * written the part that fits (it learns the size while it writes; nothing is ever written behind out_capacity_words),
+ * the two-launch routes nothing; on WAH_ERR_TIMEOUT / WAH_ERR_STREAM segments may have been written at positions
+ * derived from an unresolved count, inside the capacity. */
 int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                           uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream);
 
@@ -168,8 +185,18 @@ int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_
  * (WAH_ERR_TIMEOUT), and what WAH_FORCE_FALLBACK=1 in the environment selects for every call.  The route reads nothing
  * of the workspace's earlier content; before the scan route is used again after a WAH_ERR_TIMEOUT the workspace must be
  * initialised again (wah_workspace_init_device). */
+/* WAH_TWO_LAUNCHES: the scan of the stream (decode_sums_kernel) and the expansion (decode_expand_kernel) as two launches
+ * with waits, as _scan_device + _expand_device: the stream is read twice. */
+#define WAH_TWO_LAUNCHES 4u
 int wah_decompress_device_ex(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                              uint64_t *d_out_info, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Which decoder the calling thread's last wah_decompress* call launched: 0 none (an argument error), WAH_ROUTE_ONE_PASS,
+ * WAH_ROUTE_TWO_LAUNCHES, WAH_ROUTE_NO_WAIT. */
+#define WAH_ROUTE_ONE_PASS 1
+#define WAH_ROUTE_TWO_LAUNCHES 2
+#define WAH_ROUTE_NO_WAIT 3
+int wah_last_decode_route(void);
 
 /* Decoding through the segment index of wah_compress_device_indexed(): segments [first_segment, first_segment +
  * n_segments) of the bitmap (992 words each, the bitmap's last one shorter) are written to d_out[0 ..).  A stream of

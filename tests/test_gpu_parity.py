@@ -629,12 +629,12 @@ def test_timeout_takes_the_no_wait_route(wah, oracle, monkeypatch):
     it, and the kept workspace is usable by the next ordinary call."""
     data = oracle.gen_uniform(992 * 300 + 7, 21, 0.02)
     want = oracle.compress(data)
-    monkeypatch.setenv("WAH_TEST_TIMEOUT", "1")
+    monkeypatch.setenv("WAH_FAULT_INJECT", "timeout")
     got, t = wah.compress(data, with_timings=True)
     assert np.array_equal(got, want) and t.device_ms > 0
     back, t = wah.decompress(got, with_timings=True)
     assert np.array_equal(back[: len(data)], data) and t.device_ms > 0
-    monkeypatch.delenv("WAH_TEST_TIMEOUT")
+    monkeypatch.delenv("WAH_FAULT_INJECT")
     assert np.array_equal(wah.compress(data), want)
     assert np.array_equal(wah.decompress(want)[: len(data)], data)
 
@@ -787,12 +787,63 @@ def test_decode_mostly_empty_bitmap_with_dense_islands(wah, oracle):
     x[992 * 39000:] = 0xFFFFFFFF
     st = _py_merge_fills(oracle.compress(x))
     assert len(st) * 8 < n  # (highly compressed: not the one-pass decoder's case)
-    for no_wait in (False, True):
-        dec = wah.DeviceDecompressor(len(st), n + 1, no_wait=no_wait)
+    for kw, route in (({}, "one pass"), ({"two_launches": True}, "two launches"), ({"no_wait": True}, "no wait")):
+        dec = wah.DeviceDecompressor(len(st), n + 1, **kw)
         dec.run(_dev(st))
-        assert np.array_equal(_host(dec.result())[:n], x), no_wait
+        assert dec.route == route
+        assert np.array_equal(_host(dec.result())[:n], x), route
         dec.run(_dev(st))  # (the list's counters change hands from launch to launch)
-        assert np.array_equal(_host(dec.result())[:n], x), no_wait
+        assert np.array_equal(_host(dec.result())[:n], x), route
+
+
+def test_decoder_route_is_a_property_of_the_stream(wah, oracle):
+    """wah_decompress_device decodes in ONE pass over the stream whatever the stream and whatever capacity the caller names
+    (include/wah.h): decode_tile_kernel decides tile by tile whether it expands a tile itself or puts it on the list the launch
+    behind it shares out.  An incompressible stream with 64 times the capacity it needs, a highly compressed one with exactly
+    what it needs, a mix of both: the library reports the one-pass route (wah_last_decode_route) and the words are the
+    oracle's.  The other routes on request or by necessity: WAH_TWO_LAUNCHES, WAH_NO_WAIT, a stream that is only 4-byte
+    aligned.  And what a capacity that is too small leaves behind, route by route (d_out is undefined then, include/wah.h:
+    pinned here so that a change is seen)."""
+    import torch
+
+    n = 992 * 2600
+    dense = oracle.gen_uniform(n, 3, 0.5)
+    clustered = oracle.gen_clustered(n, 4)
+    mixed = dense.copy()
+    mixed[992 * 700: 992 * 1900] = clustered[992 * 700: 992 * 1900]
+    for name, x, cap in (("dense, 64 x the capacity", dense, 64 * n), ("clustered", clustered, n + 1), ("mixed", mixed, 3 * n)):
+        st = oracle.compress(x)
+        want = oracle.decompress(st)
+        for kw, route in (({}, "one pass"), ({"two_launches": True}, "two launches"), ({"no_wait": True}, "no wait")):
+            dec = wah.DeviceDecompressor(len(st), cap, **kw)
+            dec.run(_dev(st))
+            assert dec.route == route, (name, dec.route)
+            assert np.array_equal(_host(dec.result()), want), (name, route)
+            dec.run(_dev(st))
+            assert np.array_equal(_host(dec.result()), want), (name, route, "again")
+        # 4-byte aligned only: the scan + expansion launches, whatever was asked for
+        shifted = torch.empty(len(st) + 1, dtype=torch.int32, device="cuda")[1:]
+        shifted.copy_(_dev(st))
+        dec = wah.DeviceDecompressor(len(st), cap)
+        dec.run(shifted)
+        assert dec.route == "two launches" and np.array_equal(_host(dec.result()), want), name
+        # too small a capacity: reported by both, nothing written behind it; the two launches write nothing at all, the one-pass
+        # decoder what fits of the tiles it expands itself (all of them in the incompressible stream; the tiles on its list are
+        # expanded by the launch behind it, which knows the size and writes nothing)
+        short = 992 * 1000 + 17
+        for kw in ({}, {"two_launches": True}):
+            dec = wah.DeviceDecompressor(len(st), short, **kw)
+            whole = torch.full((short + 64,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+            dec.out = whole[:short]
+            dec.run(_dev(st))
+            with pytest.raises(wah.WahError):
+                dec.status()
+            got = _host(whole)
+            assert bool((got[short:] == 0x5A5A5A5A).all()), (name, kw)
+            if kw:
+                assert bool((got == 0x5A5A5A5A).all()), (name, "two launches write nothing")
+            elif name.startswith("dense"):
+                assert np.array_equal(got[:short], want[:short]), (name, "one pass writes the part that fits")
 
 
 def test_decode_workspace_named_with_different_sizes(wah, oracle):
@@ -804,6 +855,15 @@ def test_decode_workspace_named_with_different_sizes(wah, oracle):
 
     sizes = [992 * 40, 992 * 300 + 5, 992 * 40, 2_000_000, 992 * 40, 31, 992 * 300 + 5]
     streams = [oracle.compress(oracle.gen_uniform(n, 40 + i, 0.5 if i % 2 == 0 else 0.02)) for i, n in enumerate(sizes)]
+    # ... and foreign streams, whose tiles leave flag bytes and list entries behind (fill words of count 0, a fill of 3000
+    # segments inside incompressible data: tiles on the deferred list), between the plain ones
+    big = oracle.gen_uniform(992 * 4000, 9, 0.5)
+    big[992 * 500 + 3: 992 * 3500] = 0
+    holes = _py_merge_fills(oracle.compress(big))
+    empties = oracle.compress(oracle.gen_uniform(992 * 120, 10, 0.1)).copy()
+    empties = np.insert(empties, [5, 700, 9000, len(empties) - 1], [0x80000000, 0xC0000000, 0x80000000, 0xC0000000]).astype(np.uint32)
+    sizes = sizes[:3] + [992 * 4000, 992 * 120] + sizes[3:] + [992 * 4000]
+    streams = streams[:3] + [holes, empties] + streams[3:] + [holes]
     L = wah.lib()
     ws_max = max(int(L.wah_decompress_workspace_bytes(len(st), 0)) for st in streams)
     ws = torch.zeros(ws_max, dtype=torch.uint8, device="cuda")  # zeroed ONCE

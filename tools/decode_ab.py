@@ -1,5 +1,6 @@
 """general decode (wah_decompress_device) on the three 1 GiB bench bitmaps: ms per decode, bit-exact check against the input.
-WAH_DECODE_TWO_PASS=1 selects the sums + expand route."""
+DECODE_ROUTE=two / nowait selects the sums + expand launches (WAH_TWO_LAUNCHES / WAH_NO_WAIT); the route the library reports
+is printed."""
 import importlib, os, sys, torch
 sys.path.insert(0, "/root/repo")
 wah = importlib.import_module("gpu-wah_amd")
@@ -12,7 +13,8 @@ for kind in sys.argv[1:] or ["sparse", "clustered", "dense"]:
     comp.run(d)
     stream = comp.result().clone()
     del comp
-    dec = wah.DeviceDecompressor(stream.numel(), n + 1)
+    kw = {"two": {"two_launches": True}, "nowait": {"no_wait": True}}.get(os.environ.get("DECODE_ROUTE", ""), {})
+    dec = wah.DeviceDecompressor(stream.numel(), n + 1, **kw)
     dec.run(stream)
     back = dec.result()
     ok = bool(torch.equal(back[:n], d)) and back.numel() in (n, n + 1)
@@ -25,5 +27,5 @@ for kind in sys.argv[1:] or ["sparse", "clustered", "dense"]:
     dec.status()
     ms = ev[0].elapsed_time(ev[1]) / 20
     c = stream.numel()
-    print(f"[{tag}] {kind:9s}: {ms:.4f} ms  roofline {(4*c+4*n)/ms/1e6/8000:.3f}  {'bit-exact' if ok else 'MISMATCH'}", flush=True)
+    print(f"[{tag}] {kind:9s} ({dec.route}): {ms:.4f} ms  roofline {(4*c+4*n)/ms/1e6/8000:.3f}  {'bit-exact' if ok else 'MISMATCH'}", flush=True)
     del dec, d, stream, back
