@@ -25,9 +25,11 @@ The JSON line also carries
                  launch (4N + 4C) / its average launch duration inside the round trip, measured
                  here with device events on the stream it runs on; launch_ms_isolated = the same kernel in a
                  compress-only loop (in the round trip it starts while the expand kernel's 1 GiB of writes is still
-                 draining from the memory-side cache).  `traffic` = HBM bytes per launch from the PMC passes recorded
-                 in profiles/traffic.json (rocprofv3 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes + WRITE_SIZE):
-                 a number replayed from that profile, not counted in this run ("traffic_measured_in_run": false).
+                 draining from the memory-side cache).  `traffic` = HBM bytes per launch by the PMC counters (rocprofv3
+                 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes + WRITE_SIZE, separate passes), counted IN THIS RUN
+                 by two child runs of the same command (3 steps) under rocprofv3 before the timed process touches the GPU
+                 ("traffic_measured_in_run": true); without rocprofv3, with --no-traffic, or when a pass fails: the number
+                 recorded in profiles/traffic.json, replayed ("traffic_measured_in_run": false).
   columns      : side block (never `value`): BASELINE configs[4] measured by the same command -- this rank's share of
                  the 1024 independent 128 MiB columns, 5 steps -- with its own roofline block; --no-columns leaves it out.
   cpu_baseline : the CPU oracle (a port of the reference algorithm -- the reference has no CPU path and its CUDA
@@ -83,6 +85,7 @@ def parse(argv=None):
                     help="columns workload: HIP streams the launches are spread over (one compressor = output buffer + workspace each)")
     ap.add_argument("--cpu-sample-mib", type=int, default=1024, help="size of the CPU-baseline sample (default: the whole 1 GiB bitmap, about 10 s of host work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="do not count HBM bytes with rocprofv3 child runs (roofline.traffic is then replayed from profiles/traffic.json)")
     ap.add_argument("--no-columns", action="store_true", help="round-trip workloads: leave out the `columns` side block (configs[4])")
     ap.add_argument("--columns-steps", type=int, default=5, help="steps of the `columns` side block")
     ap.add_argument("--seed", type=int, default=1337)
@@ -202,6 +205,62 @@ def load_traffic(workload):
         return json.load(open(path)).get(workload)
     except Exception:
         return None
+
+
+def measure_traffic(args):
+    """HBM bytes per launch of the round trip's kernels, counted IN THIS RUN: two child runs of this command (3 steps) under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md prescribes;
+    FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 bytes), started before this process touches the GPU.
+    None when rocprofv3 is not there or a pass fails (the line then replays profiles/traffic.json and says so)."""
+    import collections
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None
+    raw = collections.defaultdict(dict)
+    tmp = tempfile.mkdtemp(prefix="wah_traffic_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-columns",
+                   "--no-traffic", "--workload", args.workload, "--seed", str(args.seed)]
+            if args.words:
+                cmd += ["--words", str(args.words)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            p = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            if p.returncode != 0:
+                return None
+            agg = collections.defaultdict(list)
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+                    if m and r["Counter_Name"] == counter:
+                        agg[m.group(1)].append(float(r["Counter_Value"]))
+            if not agg:
+                return None
+            for k, v in agg.items():
+                raw[k][counter] = sum(v) / len(v)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def hbm(k):
+        t = raw.get(k, {})
+        return (2.0 * t.get("FETCH_SIZE", 0.0) + t.get("WRITE_SIZE", 0.0)) * 1024.0  # (the counters are in KiB)
+
+    return {"compress_bytes_per_launch": hbm("compress_pair_kernel"),
+            "decompress_bytes_per_launch": hbm("decode_tile_kernel") + hbm("decode_expand_list_kernel") + hbm("decode_sums_kernel") + hbm("decode_expand_kernel"),
+            "decompress_indexed_bytes_per_launch": hbm("decode_segments_kernel"),
+            "source": "this run: two child runs of the same command (3 steps) under rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
+                      "(separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md; mean per launch",
+            "measured": True}
 
 
 def column_plan(n_columns, rank, world, per_launch):
@@ -495,7 +554,8 @@ def run_rank(args):
                                       "compressed stream's all, an incompressible one's none)",
                           "two launches": "decode_sums_kernel + decode_expand_kernel",
                           "no wait": "decode_sums_kernel<no wait> + sums_offsets_kernel + decode_expand_kernel"}.get(dec.route, dec.route)
-        tr = load_traffic(args.workload) or {}
+        tr = getattr(args, "traffic", None) or load_traffic(args.workload) or {}
+        measured = bool(tr.get("measured"))
         out = {
             "metric": "compress+decompress GB/s (input bits), 1 GiB bitmap",
             "value": round(world * args.steps * in_bytes / elapsed / 1e9, 3),
@@ -513,7 +573,7 @@ def run_rank(args):
             "two_round_trips_in_flight_GBps": round(two_in_flight, 1) if two_in_flight else None,
             "roofline": {"kernel": "compress_pair_kernel", "bound": "hbm", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                         "traffic": tr.get("compress_bytes_per_launch"), "traffic_measured_in_run": False,
+                         "traffic": tr.get("compress_bytes_per_launch"), "traffic_measured_in_run": measured,
                          "traffic_source": tr.get("source"),
                          "algorithmic_bytes_per_launch": algo_c, "launch_ms": round(comp_avg, 4),
                          "launch_ms_isolated": round(comp_isolated, 4),
@@ -522,13 +582,13 @@ def run_rank(args):
             "roofline_decompress": {"kernel": decode_kernels, "bound": "hbm",
                                     "achieved": round(achieved_d, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                     "frac": round(achieved_d / HBM_PEAK_GBPS, 4),
-                                    "traffic": tr.get("decompress_bytes_per_launch"), "traffic_measured_in_run": False,
+                                    "traffic": tr.get("decompress_bytes_per_launch"), "traffic_measured_in_run": measured,
                                     "algorithmic_bytes_per_launch": algo_d, "launch_ms": round(dec_avg, 4)},
             "roofline_decompress_indexed": {"kernel": "decode_segments_kernel", "bound": "hbm",
                                             "achieved": round(algo_d / (idx_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                                             "unit": "GB/s", "frac": round(algo_d / (idx_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                             "traffic": tr.get("decompress_indexed_bytes_per_launch"),
-                                            "traffic_measured_in_run": False,
+                                            "traffic_measured_in_run": measured,
                                             "algorithmic_bytes_per_launch": algo_d,
                                             "launch_ms": round(idx_ms, 4),
                                             "note": "side measurement with the segment index kept by the compressor; not part of value"},
@@ -563,6 +623,10 @@ def main(argv=None):
         print(f"bench.py: started with WORLD_SIZE={world_env} but --gpus {args.gpus}: start it with matching values "
               f"(python bench.py --gpus N starts its own ranks)", file=sys.stderr)
         return 2
+    # HBM bytes by the PMC counters, in child runs under rocprofv3, BEFORE this process touches the GPU (N = 1, real GPU only)
+    args.traffic = None
+    if args.gpus == 1 and world_env is None and not args.no_traffic and not os.environ.get("WAH_BENCH_REHEARSE") and args.workload != "columns":
+        args.traffic = measure_traffic(args)
     run_rank(args)
     return 0
 

@@ -10,6 +10,6 @@ done
 for lag in $lags; do
   for w in $kinds; do
     echo "== bench lag $lag $w"
-    WAH_DT_LAG=$lag timeout -k 10 200 python bench.py --workload $w --no-cpu-baseline --no-columns 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('decompress_ms', r['decompress_ms'], 'compress_ms', r['compress_ms'], 'value', r['value'])" || exit 1
+    WAH_DT_LAG=$lag timeout -k 10 200 python bench.py --workload $w --no-cpu-baseline --no-columns --no-traffic 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('decompress_ms', r['decompress_ms'], 'compress_ms', r['compress_ms'], 'value', r['value'])" || exit 1
   done
 done

@@ -8,10 +8,10 @@ rm -rf $out; mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 for wl in sparse clustered dense; do
   # (a) kernel trace + stats of the exact bench command
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$wl -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-columns --workload $wl > $out/bench_profiled_$wl.json 2> $out/kt_$wl.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$wl -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-columns --no-traffic --workload $wl > $out/bench_profiled_$wl.json 2> $out/kt_$wl.err
   # (b) HBM traffic: separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-columns --workload $wl > /dev/null 2> $out/pmc_${wl}_$c.err
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_${wl}_$c -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-columns --no-traffic --workload $wl > /dev/null 2> $out/pmc_${wl}_$c.err
   done
   # (c) the un-profiled bench line
   python3 $R/bench.py --steps 20 --warmup 3 --workload $wl > $out/bench_$wl.json 2> $out/bench_$wl.err
@@ -23,11 +23,49 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
            "SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_SMEM SQ_INSTS_BRANCH GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/sq_p$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-columns --workload sparse > /dev/null 2> $out/sq_p$i.err || echo "SQ pass $i failed"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $out/sq_p$i -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-columns --no-traffic --workload sparse > /dev/null 2> $out/sq_p$i.err || echo "SQ pass $i failed"
+done
+# (e) the kernels of SURVEY 8(f) on the sparse and the clustered GiB (tools/next_rows_time.py): kernel trace per workload
+for wl in sparse clustered; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_next_$wl -- python3 $R/tools/next_rows_time.py $wl > $out/next_rows_$wl.log 2> $out/kt_next_$wl.err || echo "next rows $wl failed"
 done
 python3 - <<PY
 import csv, glob, json, re, collections, os
 out = "$out"
+# ---- 8(f) rows: kernel-trace average, algorithmic bytes, fraction of 8 TB/s
+with open(f"{out}/next_rows.txt", "w") as o:
+    o.write("rocprofv3 --kernel-trace --stats -- python3 tools/next_rows_time.py <workload>   (1 GiB bitmaps, N = 268435200 words; every call 1 + 5 times)\n")
+    o.write("algorithmic bytes: unsegmented encoder 4N + 4C_u; checker / sums pass 4C; index builder 4C + 8 per segment; merge count 4C, scatter 4C + 4C_u;\n")
+    o.write("fused AND of two indexed streams 4C_A + 4C_B + 4C_out; four-operand combining pass 4(C_A + .. + C_D) + 4N (one decoded bitmap written)\n")
+    for wl in ("sparse", "clustered"):
+        meta = None
+        try:
+            for ln in open(f"{out}/next_rows_{wl}.log"):
+                if ln.startswith("NEXT_ROWS "):
+                    meta = json.loads(ln[len("NEXT_ROWS "):])
+        except Exception:
+            pass
+        if not meta:
+            o.write(f"== {wl}: no NEXT_ROWS line\n")
+            continue
+        d = collections.defaultdict(list)
+        for f in glob.glob(f"{out}/kt_next_{wl}/**/*kernel_trace.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+                if m:
+                    d[m.group(1)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        o.write(f"== {wl}: C = {meta['c_words']} words (C/N {meta['c_words']/meta['n_words']:.4f}), unsegmented {meta['c_unsegmented']} words\n")
+        for k, b in meta["algorithmic_bytes"].items():
+            v = d.get(k)
+            if not v:
+                o.write(f"  {k:30s} (not in the trace)\n")
+                continue
+            if k == "compress_pair_kernel":  # the set-up launches (making the operands) run the same kernel on other bytes
+                v = v[-6:]
+            avg = sum(v) / len(v)
+            o.write(f"  {k:30s} launches {len(v):3d}  avg {avg:9.1f} us  algorithmic {b/1e9:7.4f} GB  {b/avg/1e3:7.0f} GB/s = {b/avg/1e3/8000.0:.3f} of 8 TB/s\n")
+        o.write("  calls (ms between two events, everything the call launches): " + json.dumps(meta["call_ms"]) + "\n")
+print(open(f"{out}/next_rows.txt").read())
 summary = {}
 lines = []
 for wl in ("sparse", "clustered", "dense"):
