@@ -804,7 +804,7 @@ MergeLayout merge_layout(uint64_t c_words) {
     l.kept_off = l.decode_bytes;
     l.info_off = round256(l.kept_off + (d.n_tiles + 2) * sizeof(uint64_t));
     l.pos_off = l.info_off + 256;
-    l.total = round256(l.pos_off + (c_words + 1) * sizeof(uint64_t));
+    l.total = round256(l.pos_off + (d.n_tiles + 2) * sizeof(uint64_t)); // (one position per TILE: round 3 kept one per word)
     return l;
 }
 } // namespace
@@ -836,7 +836,7 @@ int wah_merge_fills_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d
     a.tile_base = reinterpret_cast<const uint64_t *>(ws + d.base_off);
     a.info = info;
     a.tile_kept = reinterpret_cast<uint64_t *>(ws + l.kept_off);
-    a.positions = reinterpret_cast<uint64_t *>(ws + l.pos_off);
+    a.tile_first = reinterpret_cast<uint64_t *>(ws + l.pos_off);
     a.out = d_out;
     a.out_capacity = out_capacity_words;
     a.out_words = d_out_words;

@@ -7,6 +7,37 @@
 namespace wah {
 namespace {
 
+// The sixteen consecutive words of every thread out of the workgroup's 4096-word tile (checker, index builder, merger: each
+// walks its words in stream order with a running group position).  Read as they lie -- sixteen dword loads per thread, every
+// instruction touching sixty-four addresses 64 bytes apart -- the walk kernels ran at 1.9 TB/s (profiles/r04_next_rows.txt,
+// first run); here the tile comes in by coalesced 16-byte loads (four per thread), is parked in LDS, and every thread takes
+// its sixteen words from there with four 16-byte LDS reads.  `prev` = the word in front of the thread's first one (0 in
+// front of the stream).  Streams that are only 4-byte aligned and the stream's last tile: dword loads, bounds checked;
+// words behind the stream's end read as fills of count 0 (nothing).
+constexpr u32 kWalkWords = (u32)kExpandWordsPerThread;
+__device__ __forceinline__ void walk_load_tile(const u32 *comp, u64 c_words, u32 tile, u32 *s_tile /* kScanTileWords */, u32 (&w)[kWalkWords],
+                                               u32 &prev) {
+    const u64 tile_w0 = (u64)tile * kScanTileWords;
+    if ((reinterpret_cast<uintptr_t>(comp) & 15u) == 0 && tile_w0 + kScanTileWords <= c_words) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(comp + tile_w0);
+        u32x4 v[kWalkWords / 4];
+#pragma unroll
+        for (u32 k = 0; k < kWalkWords / 4; ++k) v[k] = __builtin_nontemporal_load(src + k * kExpandThreads + threadIdx.x);
+#pragma unroll
+        for (u32 k = 0; k < kWalkWords / 4; ++k) reinterpret_cast<u32x4 *>(s_tile)[k * kExpandThreads + threadIdx.x] = v[k];
+    } else {
+        for (u32 i = threadIdx.x; i < (u32)kScanTileWords; i += kExpandThreads) s_tile[i] = tile_w0 + i < c_words ? comp[tile_w0 + i] : 0x80000000u;
+    }
+    __syncthreads();
+    const uint4 *mine = reinterpret_cast<const uint4 *>(s_tile + threadIdx.x * kWalkWords);
+#pragma unroll
+    for (u32 k = 0; k < kWalkWords / 4; ++k) {
+        const uint4 q = mine[k];
+        w[4 * k] = q.x, w[4 * k + 1] = q.y, w[4 * k + 2] = q.z, w[4 * k + 3] = q.w;
+    }
+    prev = threadIdx.x ? s_tile[threadIdx.x * kWalkWords - 1u] : (tile_w0 > 0 && tile_w0 - 1 < c_words ? comp[tile_w0 - 1] : 0u);
+}
+
 // ===========================================================================
 // stream checker (include/wah.h: wah_validate_device).  One workgroup per 4096-word tile, after the sums pass: the
 // tile bases give every word its group position, so the per-word properties that depend on position (a fill crossing
@@ -15,24 +46,23 @@ namespace {
 __global__ __launch_bounds__(kExpandThreads) void validate_kernel(const u32 *comp, u64 c_words, const u64 *tile_base,
                                                                   const u64 *info, u64 *report) {
     __shared__ u64 s_wave_sum[kExpandWaves];
+    __shared__ __attribute__((aligned(16))) u32 s_tile[kScanTileWords];
     const u32 lane = lane_id();
     const u32 wave = wave_id();
     const u32 tile = blockIdx.x;
     const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread; // my 16 consecutive words
     u32 w[kExpandWordsPerThread];
+    u32 prev; // the word in front of mine (a literal 0 if none)
+    walk_load_tile(comp, c_words, tile, s_tile, w, prev);
     u64 mine = 0;
 #pragma unroll
-    for (int k = 0; k < kExpandWordsPerThread; ++k) {
-        w[k] = w0 + k < c_words ? comp[w0 + k] : 0x80000000u; // past the end: nothing
-        mine += word_groups(w[k]);
-    }
+    for (int k = 0; k < kExpandWordsPerThread; ++k) mine += word_groups(w[k]);
     const u64 incl = wave_scan_incl(mine, lane);
     if (lane == 63) s_wave_sum[wave] = incl;
     __syncthreads();
     u64 p = tile_base[tile] + (incl - mine); // group position of my first word
     for (u32 k = 0; k < wave; ++k) p += s_wave_sum[k];
 
-    u32 prev = w0 > 0 && w0 - 1 < c_words ? comp[w0 - 1] : 0u; // the word in front of mine (a literal 0 if none)
     const bool have_prev = w0 > 0;
     u32 n_empty = 0, n_litfill = 0, n_cross = 0, n_unmerged = 0;
 #pragma unroll
@@ -72,17 +102,17 @@ __global__ __launch_bounds__(kExpandThreads) void validate_kernel(const u32 *com
 __global__ __launch_bounds__(kExpandThreads) void index_kernel(const u32 *comp, u64 c_words, const u64 *tile_base, const u64 *info,
                                                                u64 *offsets, u64 capacity, u32 *ctrl) {
     __shared__ u64 s_wave_sum[kExpandWaves];
+    __shared__ __attribute__((aligned(16))) u32 s_tile[kScanTileWords];
     const u32 lane = lane_id();
     const u32 wave = wave_id();
     const u32 tile = blockIdx.x;
     const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread; // my 16 consecutive words
     u32 w[kExpandWordsPerThread];
+    u32 prev_unused;
+    walk_load_tile(comp, c_words, tile, s_tile, w, prev_unused);
     u64 mine = 0;
 #pragma unroll
-    for (int k = 0; k < kExpandWordsPerThread; ++k) {
-        w[k] = w0 + k < c_words ? comp[w0 + k] : 0x80000000u; // past the end: nothing
-        mine += word_groups(w[k]);
-    }
+    for (int k = 0; k < kExpandWordsPerThread; ++k) mine += word_groups(w[k]);
     const u64 incl = wave_scan_incl(mine, lane);
     if (lane == 63) s_wave_sum[wave] = incl;
     __syncthreads();
@@ -183,21 +213,18 @@ struct MergeTile {
     bool have_prev;
 };
 
-__device__ __forceinline__ void merge_load_tile(const MergeArgs &a, u32 tile, u64 *s_wave_sum, u32 lane, u32 wave, MergeTile &t) {
+__device__ __forceinline__ void merge_load_tile(const MergeArgs &a, u32 tile, u64 *s_wave_sum, u32 *s_tile, u32 lane, u32 wave, MergeTile &t) {
     const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread;
+    walk_load_tile(a.comp, a.c_words, tile, s_tile, t.w, t.prev);
     u64 mine = 0;
 #pragma unroll
-    for (int k = 0; k < kExpandWordsPerThread; ++k) {
-        t.w[k] = w0 + k < a.c_words ? a.comp[w0 + k] : 0x80000000u; // past the end: nothing
-        mine += word_groups(t.w[k]);
-    }
+    for (int k = 0; k < kExpandWordsPerThread; ++k) mine += word_groups(t.w[k]);
     const u64 incl = wave_scan_incl(mine, lane);
     if (lane == 63) s_wave_sum[wave] = incl;
     __syncthreads();
     t.p = a.tile_base[tile] + (incl - mine);
     for (u32 k = 0; k < wave; ++k) t.p += s_wave_sum[k];
     t.have_prev = w0 > 0;
-    t.prev = w0 > 0 && w0 - 1 < a.c_words ? a.comp[w0 - 1] : 0u;
 }
 
 // is word x (at group position p, behind word prev) dropped?
@@ -211,30 +238,67 @@ __device__ __forceinline__ bool merge_dropped(u32 x, u32 prev, bool have_prev, u
     return ((p - pcnt) >> kMergeBlockShift) == ((p + cnt - 1u) >> kMergeBlockShift);
 }
 
+// u64 minimum over the wave (every lane gets it) and the minimum over the lanes BEHIND mine (~0 if none)
+__device__ __forceinline__ u64 wave_min64(u64 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 t = __shfl_xor(v, off);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 wave_suffix_min_excl64(u64 v, u32 lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { // inclusive suffix minimum
+        const u64 t = __shfl_down(v, off);
+        if (lane + (u32)off < 64u && t < v) v = t;
+    }
+    const u64 next = __shfl_down(v, 1);
+    return lane < 63u ? next : ~0ull;
+}
+
+// pass 1: per tile the number of kept words and the group position of its FIRST kept word (~0: none)
 __global__ __launch_bounds__(kExpandThreads) void merge_count_kernel(const MergeArgs a) {
     __shared__ u64 s_wave_sum[kExpandWaves];
     __shared__ u32 s_kept[kExpandWaves];
+    __shared__ u64 s_first[kExpandWaves];
+    __shared__ __attribute__((aligned(16))) u32 s_tile[kScanTileWords];
     const u32 lane = lane_id(), wave = wave_id(), tile = blockIdx.x;
     MergeTile t;
-    merge_load_tile(a, tile, s_wave_sum, lane, wave, t);
+    merge_load_tile(a, tile, s_wave_sum, s_tile, lane, wave, t);
     const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread;
     u32 kept = 0, prev = t.prev;
     bool have_prev = t.have_prev;
-    u64 p = t.p;
+    u64 p = t.p, first = ~0ull;
 #pragma unroll
     for (int k = 0; k < kExpandWordsPerThread; ++k) {
-        if (w0 + k < a.c_words) kept += !merge_dropped(t.w[k], prev, have_prev, p);
+        if (w0 + k < a.c_words && !merge_dropped(t.w[k], prev, have_prev, p)) {
+            if (kept == 0) first = p;
+            ++kept;
+        }
         p += word_groups(t.w[k]);
         prev = t.w[k];
         have_prev = true;
     }
     const u32 wk = wave_sum32(kept);
-    if (lane == 0) s_kept[wave] = wk;
+    const u64 wf = wave_min64(first);
+    if (lane == 0) {
+        s_kept[wave] = wk;
+        s_first[wave] = wf;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) a.tile_kept[tile] = (u64)s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
+    if (threadIdx.x == 0) {
+        a.tile_kept[tile] = (u64)s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
+        u64 f = s_first[0];
+#pragma unroll
+        for (u32 w = 1; w < kExpandWaves; ++w) f = s_first[w] < f ? s_first[w] : f;
+        a.tile_first[tile] = f;
+    }
 }
 
-// exclusive scan of tile_kept[0 .. n_tiles) in place, total into tile_kept[n_tiles] and *out_words (one workgroup)
+// one workgroup: exclusive scan of tile_kept[0 .. n_tiles) in place, total into tile_kept[n_tiles] and *out_words; then, from
+// the back, tile_first[t] := the position of the first kept word in any tile BEHIND t (the stream's group total behind the last
+// one) -- what a tile's last kept fill runs up to
 __global__ __launch_bounds__(1024) void merge_scan_kernel(const MergeArgs a) {
     __shared__ u64 s_part[16];
     __shared__ u64 s_carry;
@@ -259,62 +323,95 @@ __global__ __launch_bounds__(1024) void merge_scan_kernel(const MergeArgs a) {
         a.tile_kept[a.n_tiles] = total;
         *a.out_words = total;
         if (total > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+        s_carry = a.info[1]; // behind the last tile: the end of the stream
+    }
+    __syncthreads();
+    const u64 chunks = (a.n_tiles + 1023) / 1024;
+    for (u64 c = chunks; c-- > 0;) {
+        const u64 i = c * 1024 + threadIdx.x;
+        const u64 v = i < a.n_tiles ? a.tile_first[i] : ~0ull;
+        u64 behind = wave_suffix_min_excl64(v, lane);      // ... in my wave
+        const u64 wave_all = wave_min64(v);
+        if (lane == 0) s_part[wave] = wave_all;
+        __syncthreads();
+        for (u32 k = wave + 1; k < 16; ++k) behind = s_part[k] < behind ? s_part[k] : behind; // ... in the waves behind mine
+        const u64 carry = s_carry;                                                          // ... in the chunks behind this one
+        if (i < a.n_tiles) a.tile_first[i] = behind < carry ? behind : carry;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 m = carry;
+            for (u32 k = 0; k < 16; ++k) m = s_part[k] < m ? s_part[k] : m;
+            s_carry = m;
+        }
+        __syncthreads();
     }
 }
 
+// pass 2: every kept word to its place, a kept fill with its final count -- the distance to the next kept word, in the thread,
+// behind it in the wave / the tile (suffix minima of the first kept positions) or in a later tile (tile_first, as left by the
+// scan).  The tile's kept words are collected in LDS and leave as one coalesced run.  (Round 3: an 8-byte position per kept
+// word written beside the words and read back by a fix-up launch: 1.26 ms for the sparse GiB's stream, 0.10 of the roofline.)
 __global__ __launch_bounds__(kExpandThreads) void merge_scatter_kernel(const MergeArgs a) {
     __shared__ u64 s_wave_sum[kExpandWaves];
     __shared__ u32 s_kept[kExpandWaves];
+    __shared__ u64 s_first[kExpandWaves];
+    __shared__ __attribute__((aligned(16))) u32 s_tile[kScanTileWords];
     const u32 lane = lane_id(), wave = wave_id(), tile = blockIdx.x;
     MergeTile t;
-    merge_load_tile(a, tile, s_wave_sum, lane, wave, t);
+    merge_load_tile(a, tile, s_wave_sum, s_tile, lane, wave, t);
     const u64 w0 = (u64)tile * kScanTileWords + (u64)threadIdx.x * kExpandWordsPerThread;
-    bool keep[kExpandWordsPerThread];
+    u32 keep = 0; // bit k: word k is kept
     u64 pos[kExpandWordsPerThread];
     u32 kept = 0, prev = t.prev;
     bool have_prev = t.have_prev;
-    u64 p = t.p;
+    u64 p = t.p, first = ~0ull;
 #pragma unroll
     for (int k = 0; k < kExpandWordsPerThread; ++k) {
-        keep[k] = w0 + k < a.c_words && !merge_dropped(t.w[k], prev, have_prev, p);
         pos[k] = p;
-        kept += keep[k];
+        if (w0 + k < a.c_words && !merge_dropped(t.w[k], prev, have_prev, p)) {
+            if (kept == 0) first = p;
+            keep |= 1u << k;
+            ++kept;
+        }
         p += word_groups(t.w[k]);
         prev = t.w[k];
         have_prev = true;
     }
     const u32 incl = wave_scan_incl32(kept);
+    u64 next = wave_suffix_min_excl64(first, lane); // the first kept word behind my sixteen: in my wave ...
+    const u64 wf = wave_min64(first);
     if (lane == 63) s_kept[wave] = incl;
-    __syncthreads();
-    u64 idx = a.tile_kept[tile] + (incl - kept);
+    if (lane == 0) s_first[wave] = wf;
+    __syncthreads(); // (every thread has taken its words out of s_tile: merge_load_tile ends with a barrier, and this is the next one)
+    for (u32 k = wave + 1; k < kExpandWaves; ++k) next = s_first[k] < next ? s_first[k] : next; // ... in the waves behind mine ...
+    const u64 tile_next = a.tile_first[tile];                                                    // ... in the tiles behind this one
+    next = next < tile_next ? next : tile_next;
+    u32 idx = incl - kept; // tile-local place of my first kept word
     for (u32 k = 0; k < wave; ++k) idx += s_kept[k];
+    u32 total = 0;
 #pragma unroll
-    for (int k = 0; k < kExpandWordsPerThread; ++k) {
-        if (keep[k]) {
-            if (idx < a.out_capacity) {
-                a.out[idx] = t.w[k];
-                a.positions[idx] = pos[k];
+    for (u32 k = 0; k < kExpandWaves; ++k) total += s_kept[k];
+    // from the back: the word behind a kept word is known when the kept word is written
+    idx += kept;
+    bool bad = false;
+#pragma unroll
+    for (int k = kExpandWordsPerThread - 1; k >= 0; --k) {
+        if (keep & (1u << k)) {
+            u32 x = t.w[k];
+            if ((x & kFillZero) && (x & kCountMask)) {
+                const u64 cnt = next - pos[k];
+                bad |= cnt > kCountMask; // cannot happen: runs do not cross 2^29-group blocks
+                x = (x & ~kCountMask) | ((u32)cnt & kCountMask);
             }
-            ++idx;
+            s_tile[--idx] = x;
+            next = pos[k];
         }
     }
-}
-
-// a kept fill covers everything up to the next kept word
-__global__ void merge_fix_kernel(const MergeArgs a) {
-    const u64 kept = a.tile_kept[a.n_tiles] < a.out_capacity ? a.tile_kept[a.n_tiles] : a.out_capacity;
-    const u64 groups = a.info[1];
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < kept; i += (u64)gridDim.x * blockDim.x) {
-        const u32 x = a.out[i];
-        if ((x & kFillZero) && (x & kCountMask)) {
-            const u64 next = i + 1 < a.tile_kept[a.n_tiles] && i + 1 < a.out_capacity ? a.positions[i + 1] : groups;
-            const u64 cnt = next - a.positions[i];
-            if (cnt > kCountMask)
-                atomicOr(a.ctrl + kCtlError, kErrStream); // cannot happen: runs do not cross 2^29-group blocks
-            else if ((u32)cnt != (x & kCountMask))
-                a.out[i] = (x & ~kCountMask) | (u32)cnt;
-        }
-    }
+    if (__any(bad) && lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+    __syncthreads();
+    const u64 out0 = a.tile_kept[tile];
+    for (u32 i = threadIdx.x; i < total; i += kExpandThreads)
+        if (out0 + i < a.out_capacity) a.out[out0 + i] = s_tile[i];
 }
 
 hipError_t launch_merge_fills(const MergeArgs &a, hipStream_t s) {
@@ -325,7 +422,6 @@ hipError_t launch_merge_fills(const MergeArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(merge_count_kernel, dim3((unsigned)a.n_tiles), dim3(kExpandThreads), 0, s, a);
     hipLaunchKernelGGL(merge_scan_kernel, dim3(1), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(merge_scatter_kernel, dim3((unsigned)a.n_tiles), dim3(kExpandThreads), 0, s, a);
-    hipLaunchKernelGGL(merge_fix_kernel, dim3(2048), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

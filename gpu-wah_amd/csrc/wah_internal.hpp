@@ -226,7 +226,7 @@ hipError_t launch_build_index(const uint32_t *comp, uint64_t c_words, const uint
 hipError_t launch_decode_segments(const SegmentsArgs &a, hipStream_t s);
 hipError_t launch_bitop_many_segments(const BitopManyArgs &a, hipStream_t s);
 
-// wah_merge_fills_device (after the sums pass): kept-word counts per tile, their scan, scatter, count fix-up
+// wah_merge_fills_device (after the sums pass): kept-word counts and first kept positions per tile, their scans, scatter
 struct MergeArgs {
     const uint32_t *comp;
     uint64_t c_words;
@@ -234,7 +234,7 @@ struct MergeArgs {
     const uint64_t *tile_base; // groups in front of every tile (sums pass)
     const uint64_t *info;      // [decoded words, groups] (sums pass)
     uint64_t *tile_kept;       // n_tiles + 1: kept words per tile, then their exclusive scan
-    uint64_t *positions;       // group position of every kept word (c_words entries)
+    uint64_t *tile_first;      // n_tiles: group position of a tile's first kept word, then of the first kept word BEHIND the tile
     uint32_t *out;
     uint64_t out_capacity;
     uint64_t *out_words;
