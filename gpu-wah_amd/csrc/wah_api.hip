@@ -76,7 +76,7 @@ CompressLayout compress_layout(uint64_t n_words, size_t workspace_bytes = 0) {
 
 struct DecodeLayout {
     uint64_t n_tiles;
-    size_t ctrl_off, desc_off, base_off, flags_off, defer_off, half, total, scan_bytes;
+    size_t ctrl_off, desc_off, base_off, flags_off, defer_off, bucket_off, half, total, scan_bytes;
 };
 
 // first half: scan area of the sums kernel / of the one-pass decoder (one block per 64 x 256 workgroup tiles, + the one a full
@@ -90,7 +90,9 @@ DecodeLayout decode_layout(uint64_t c_words, size_t workspace_bytes = 0) {
     const size_t scan_need = blocks * wah::kSumScanBlockWords * sizeof(uint32_t);
     const size_t base_bytes = round256((l.n_tiles + 4) * sizeof(uint64_t)); // (+ two words for wah_validate_device)
     const size_t flag_bytes = round256(l.n_tiles + 16);                       // one byte per tile: contains empty fills
-    const size_t rest_need = base_bytes + flag_bytes + round256((size_t)wah::decode_defer_capacity(l.n_tiles, c_words) * 2 * sizeof(uint64_t)); // + the list of deferred / shared-out tiles
+    const size_t defer_bytes = round256((size_t)wah::decode_defer_capacity(l.n_tiles, c_words) * 2 * sizeof(uint64_t)); // the list of deferred / shared-out tiles
+    const size_t bucket_bytes = round256((l.n_tiles + 1) * 64 * sizeof(uint32_t)); // ... and their sums of group counts per 64 words
+    const size_t rest_need = base_bytes + flag_bytes + defer_bytes + bucket_bytes;
     const size_t need_half = round256(scan_need > rest_need ? scan_need : rest_need);
     l.ctrl_off = 0;
     l.desc_off = wah::kCtlWords * sizeof(uint32_t);
@@ -101,6 +103,7 @@ DecodeLayout decode_layout(uint64_t c_words, size_t workspace_bytes = 0) {
     l.base_off = l.desc_off + l.half;
     l.flags_off = l.base_off + base_bytes;
     l.defer_off = l.flags_off + flag_bytes; // the list (its counters: kCtlDefer in the control block)
+    l.bucket_off = l.defer_off + defer_bytes;
     if (l.half < need_half) l.total = w + 1;
     return l;
 }
@@ -640,6 +643,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
         x.ctrl = a.ctrl;
         x.aligned16 = 1;
         x.parts = 1;
+        x.tile_buckets = reinterpret_cast<const uint32_t *>(ws + l.bucket_off);
         e = wah::launch_decode_tiles(a, x, reinterpret_cast<uint64_t *>(ws + l.defer_off), s);
         if (e != hipSuccess) {
             set_err("decode tile kernel launch", e);

@@ -215,13 +215,13 @@ __device__ __forceinline__ u64 *defer_counters_mine(u32 *c) {
 // holds ONE entry per tile whatever the size of the output.  Slot and sum come out of ONE 64-bit atomic, so the entries
 // are SORTED by their sums: work item k of the launch finds its entry by search (expand_list).  c = the launch's counter
 // pair (defer_counters_mine).  false: the list is full (the tile is not on it).
-__device__ __forceinline__ bool dt_defer(u64 *c, u64 *list, u32 capacity, u64 tile, u64 groups) {
+__device__ __forceinline__ bool dt_defer(u64 *c, u64 *list, u32 capacity, u64 tile, u64 groups, bool buckets = false) {
     const u64 segs = groups / kSegGroups + 2ull;
     const u32 parts = segs >= (u64)kDeferPartSegs * 65536ull ? 65536u : (u32)((segs + kDeferPartSegs - 1ull) / kDeferPartSegs);
     const u64 old = __hip_atomic_fetch_add(c, 1ull | ((u64)parts << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const u32 slot = (u32)old;
     if (slot >= capacity) return false; // (also: a counter that did not start at zero must not lead outside the list)
-    list[2ull * slot] = tile | ((u64)parts << 32);
+    list[2ull * slot] = tile | ((u64)(parts | (buckets ? kDeferBuckets : 0u)) << 32);
     list[2ull * slot + 1] = old >> 32;
     return true;
 }
@@ -655,7 +655,13 @@ __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, u32 *s_
 
 // one expand tile (4096 words of the stream): the output segments that start inside it (every parts-th batch of them).
 // (The LDS arrays are this function's own: decode_expand_kernel and decode_expand_list_kernel each inline it once.)
-__device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 part, u32 parts) {
+// kContiguous (the list's launch): part p = the kDeferPartSegs CONSECUTIVE segments p of the tile, not every parts-th group of
+// four -- and with `buckets` (the tile's 64 sums of group counts per 64 words, left by decode_tile_kernel) the workgroup stages
+// only the words those segments need instead of the whole tile: a tile of a highly compressed stream is shared by eight or
+// more work items, each of which used to read all 16 KiB of it and count them (a quarter of the item's life, 1.13 x the
+// algorithmic traffic on the clustered GiB).
+template <bool kContiguous>
+__device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 part, u32 parts, const u32 *buckets) {
     __shared__ __attribute__((aligned(16))) u32 s_words[kTileLdsWords];
     __shared__ u64 s_coarse[kCoarse + 1]; // groups in front of word 64 c, relative to the tile start
     __shared__ u32 s_coarse32[kCoarse + 1]; // the same in 32 bits (valid when the tile total is below 2^31)
@@ -677,6 +683,50 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
         return;
     }
 
+    // ---- with bucket sums: the coarse prefix is their scan, and only the words of this part's segments are staged ---------
+    __shared__ u32 s_partial; // 1: the coarse prefix is made, the part's words are staged
+    bool partial = false;
+    if (kContiguous && buckets != nullptr) {
+        if (wave == 0) {
+            const u32 v = buckets[lane];
+            const bool sat = __any(v == kBucketSaturated);
+            const u32 incl_b = wave_scan_incl32(sat ? 0u : v);
+            s_coarse[lane] = incl_b - v;
+            s_coarse32[lane] = incl_b - v;
+            if (lane == 63) {
+                s_coarse[kCoarse] = incl_b;
+                s_coarse32[kCoarse] = incl_b;
+                s_partial = sat ? 0u : 1u;
+            }
+        }
+        __syncthreads();
+        partial = uniform32(s_partial) != 0u;
+    }
+    if (partial) {
+        const u64 base_p = a.tile_base[tile];
+        const u32 total_p = uniform32(s_coarse32[kCoarse]); // (< 2^31: no bucket is saturated)
+        const u64 kb = (base_p + kSegGroups - 1) / kSegGroups;
+        const u64 ke = (base_p + total_p + kSegGroups - 1) / kSegGroups;
+        const u64 s0 = kb + (u64)kDeferPartSegs * part;
+        const u64 s1 = s0 + kDeferPartSegs < ke ? s0 + kDeferPartSegs : ke;
+        if (s0 >= s1) return; // (wave-uniform; dt_defer's parts are an upper bound)
+        const u32 t0 = (u32)(s0 * kSegGroups - base_p);                                   // first group needed (< total)
+        const u64 t1_64 = s1 * kSegGroups - base_p;
+        const u32 t1 = t1_64 < total_p ? (u32)t1_64 : total_p;                             // one behind the last group needed of THIS tile
+        const u32 c = lane < kCoarse ? s_coarse32[lane] : 0xFFFFFFFFu;
+        const u32 b0 = (u32)__popcll(__ballot(lane < kCoarse && c <= t0)) - 1u;            // bucket of the first group
+        const u32 b1 = (u32)__popcll(__ballot(lane < kCoarse && c < t1)) - 1u;             // bucket of the last one
+        // (+ one marking batch of 128 words: mark_pairs reads whole batches from the segment's bucket on)
+        const u32 w_lo = 64u * b0, w_hi = 64u * (b1 + 1u) + 128u < (u32)kScanTileWords ? 64u * (b1 + 1u) + 128u : (u32)kScanTileWords;
+        if (a.aligned16 && tile_w0 + kScanTileWords <= a.c_words) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(a.comp + tile_w0);
+            uint4 *dst = reinterpret_cast<uint4 *>(s_words);
+            for (u32 i = w_lo / 4u + threadIdx.x; i < w_hi / 4u; i += kExpandThreads) dst[i] = src[i];
+        } else {
+            for (u32 i = w_lo + threadIdx.x; i < w_hi; i += kExpandThreads) s_words[i] = tile_w0 + i < a.c_words ? a.comp[tile_w0 + i] : 0x80000000u;
+        }
+        __syncthreads();
+    } else {
     // ---- stage the tile and build the coarse prefix of group counts --------------------------------------------
     constexpr int kVec = kExpandWordsPerThread / 4;
     if (a.aligned16 && tile_w0 + kScanTileWords <= a.c_words) {
@@ -718,6 +768,7 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
         s_coarse32[kCoarse] = (u32)(excl + mine);
     }
     __syncthreads();
+    }
 
 #ifdef WAH_DIAG
     const u64 dg_ready = __builtin_amdgcn_s_memrealtime();
@@ -735,15 +786,20 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
         // count 0 (found by the sums pass): index-map route, one wavefront per workgroup, the four flag areas together
         // hold its 1024-entry index map
         static_assert(sizeof(s_flag) >= kSegGroups * sizeof(u32), "index map must fit the flag areas");
-        if (wave == 0)
-            for (u64 seg = k_begin + part; seg < k_end; seg += parts)
+        if (wave == 0) {
+            const u64 e_first = kContiguous ? k_begin + (u64)kDeferPartSegs * part : k_begin + part;
+            const u64 e_last = kContiguous && e_first + kDeferPartSegs < k_end ? e_first + kDeferPartSegs : k_end;
+            for (u64 seg = e_first; seg < e_last; seg += kContiguous ? 1u : parts)
                 expand_segment_with_empties(a, s_words, s_coarse, reinterpret_cast<u32 *>(&s_flag[0][0]), tile_w0, base, groups,
                                             out_words, seg, lane);
+        }
         return;
     }
     unsigned char *flag = s_flag[wave];
     const bool tame = total < (1ull << 31); // wave-uniform: positions inside this tile fit 32 bits
-    for (u64 seg = k_begin + wave + (u64)kExpandWaves * part; seg < k_end; seg += (u64)kExpandWaves * parts) {
+    const u64 seg_first = kContiguous ? k_begin + (u64)kDeferPartSegs * part + wave : k_begin + wave + (u64)kExpandWaves * part;
+    const u64 seg_last = kContiguous && k_begin + (u64)kDeferPartSegs * (part + 1u) < k_end ? k_begin + (u64)kDeferPartSegs * (part + 1u) : k_end;
+    for (u64 seg = seg_first; seg < seg_last; seg += kContiguous ? (u64)kExpandWaves : (u64)kExpandWaves * parts) {
         if (tame) {
             const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
             expand_segment_tame(a, s_words, s_coarse32, flag, tile_w0, (u32)(seg * kSegGroups - base), nvalid, out_words, seg, lane);
@@ -803,11 +859,12 @@ __device__ __forceinline__ void expand_list(const ExpandArgs &a, const u64 *list
         if (below == 0u) continue; // (a list that is not what dt_defer wrote)
         const u32 e = uniform32(lo + below - 1u);
         const u64 entry = list[2ull * e];
-        const u32 tile = uniform32((u32)entry), parts = uniform32((u32)(entry >> 32)), part = k - uniform32((u32)list[2ull * e + 1]);
+        const u32 tile = uniform32((u32)entry), parts = uniform32((u32)(entry >> 32)) & ~kDeferBuckets, part = k - uniform32((u32)list[2ull * e + 1]);
+        const bool buckets = (uniform32((u32)(entry >> 32)) & kDeferBuckets) != 0u && a.tile_buckets != nullptr;
         if (tile >= n_et || parts == 0u || parts > 65536u || part >= parts) continue;
         if (listed_tile_is_regular(a, tile, regular_parts)) continue;
         if (k != w) __syncthreads(); // the LDS image goes to the next tile
-        expand_tile(a, tile, part, parts);
+        expand_tile<true>(a, tile, part, parts, buckets ? a.tile_buckets + (u64)tile * kCoarse : nullptr);
     }
 }
 
@@ -822,12 +879,15 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
         if (threadIdx.x == 0 && a.info[0] > a.out_capacity) atomicOr(a.ctrl + kCtlError, kErrCapacity);
         return;
     }
-    expand_tile(a, tile, blockIdx.x % a.parts, a.parts);
+    expand_tile<false>(a, tile, blockIdx.x % a.parts, a.parts, nullptr);
 }
 
+#ifndef WAH_LIST_MINW
+#define WAH_LIST_MINW 5 // (inlined inside the loop over work items the tile routine wants 123 registers; capped at 95 it spills nothing: five waves per SIMD)
+#endif
 // the expand tiles decode_tile_kernel left to this route (giant fills, fill words of count 0: foreign streams), out of its
 // list; normally the list is empty and the launch ends at once.
-__global__ __launch_bounds__(kExpandThreads) void decode_expand_list_kernel(const ExpandArgs a, const u64 *list, const u32 *count, u32 capacity, u32 regular_parts) {
+__global__ __launch_bounds__(kExpandThreads, WAH_LIST_MINW) void decode_expand_list_kernel(const ExpandArgs a, const u64 *list, const u32 *count, u32 capacity, u32 regular_parts) {
     expand_list(a, list, count, capacity, blockIdx.x, gridDim.x, regular_parts);
 }
 
@@ -1089,6 +1149,7 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *de
     t.defer_count = sa.ctrl + kCtlDefer; // (wah_internal.hpp)
     t.defer_list = defer;
     t.defer_capacity = decode_defer_capacity(sa.n_tiles, sa.c_words);
+    t.tile_buckets = const_cast<u32 *>(xa.tile_buckets);
     t.ctrl = sa.ctrl;
     t.gen_desc = sa.gen_desc;
     t.scan_words = sa.scan_words;

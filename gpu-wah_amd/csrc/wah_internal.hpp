@@ -54,6 +54,8 @@ constexpr uint32_t kCtlDefer = 192;      // the decoders' list of tiles that are
                                          // lies depends on the size of the workspace a call names, and a counter at a place that moves
                                          // would be found holding an earlier call's data
 constexpr uint32_t kDeferSeq = 4;
+constexpr uint32_t kDeferBuckets = 0x80000000u; // in a list entry's parts field: the tile's bucket sums are in tile_buckets
+constexpr uint32_t kBucketSaturated = 0xFFFFFFFFu; // a bucket holding a count above 2^25: the tile is staged whole
 constexpr uint32_t kDeferPartSegs = 32;  // output segments per work item of the list's launch (eight per wave: the chip writes faster the
                                          // shorter its waves live, tools/expand_want_sweep.sh)
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
@@ -165,6 +167,9 @@ struct ExpandArgs {
     const uint32_t *defer_count; // control block, kCtlDefer
     uint32_t defer_capacity;
     uint32_t n_tile_wgs;        // workgroups in front of them: tiles x parts (set by the launcher)
+    const uint32_t *tile_buckets; // per expand tile 64 sums of group counts, one per 64 words (kBucketSaturated: no sum), written by
+                                  // decode_tile_kernel for the tiles it puts on the list with kDeferBuckets: a work item of the list's
+                                  // launch then stages only the words its segments need
 };
 
 // wah_decompress_segments_device: decode a range of segments through the index of wah_compress_device_indexed
