@@ -846,6 +846,38 @@ def test_decoder_route_is_a_property_of_the_stream(wah, oracle):
                 assert np.array_equal(got[:short], want[:short]), (name, "one pass writes the part that fits")
 
 
+def test_decode_listed_tiles_stage_only_their_words(wah, oracle):
+    """A tile that decode_tile_kernel puts on its list carries 64 sums of group counts (one per 64 words), and a work item of
+    the list's launch stages only the words of its own 32 segments.  The shapes that decide: a highly compressed stream (every
+    tile listed, the last one partly behind the stream's end), the same with fill words of count 0 strewn in (the index-map
+    route of a listed tile), classic WAH with a fill of 40 million groups (a bucket that cannot hold its sum: the tile is staged
+    whole) next to ordinary listed tiles, and short fills only (tiles just above the kernel's own limit of about seven groups
+    per word)."""
+    rng = np.random.default_rng(3)
+    n = 992 * 3000 + 7
+    clustered = oracle.gen_clustered(n, 31)
+    st = oracle.compress(clustered)
+    cases = [("clustered", st, clustered)]
+    holes = np.sort(rng.choice(len(st), 40, replace=False))
+    with_empties = np.insert(st, holes, np.where(np.arange(40) % 2 == 0, 0x80000000, 0xC0000000).astype(np.uint32)).astype(np.uint32)
+    cases.append(("clustered + empty fills", with_empties, clustered))
+    big = np.zeros(992 * 44000, np.uint32)                      # 45 million groups of zeros ...
+    big[992 * 100: 992 * 400] = oracle.gen_clustered(992 * 300, 32)  # ... around a clustered and an incompressible stretch
+    big[992 * 43000: 992 * 43100] = oracle.gen_uniform(992 * 100, 33, 0.5)
+    cases.append(("classic WAH, a fill of 40 M groups", _py_merge_fills(oracle.compress(big)), big))
+    runs = np.repeat(rng.integers(0, 2, n // 8 + 1).astype(np.uint32) * np.uint32(0xFFFFFFFF), 8)[:n].copy()  # runs of 256 bits
+    cases.append(("runs of eight words", oracle.compress(runs), runs))
+    for name, stream, x in cases:
+        want = oracle.decompress(stream)
+        assert np.array_equal(want[: x.size], x), name
+        for cap in (want.size, want.size + 1, 5 * want.size):
+            dec = wah.DeviceDecompressor(len(stream), cap)
+            for _ in range(2):
+                dec.run(_dev(stream))
+                assert dec.route == "one pass"
+                assert np.array_equal(_host(dec.result()), want), (name, cap)
+
+
 def test_decode_workspace_named_with_different_sizes(wah, oracle):
     """One decode workspace BUFFER, handed over with the size each stream needs (what the host entry points do with the
     buffer they keep): the areas behind the control block then lie elsewhere from call to call, and nothing in them may be
