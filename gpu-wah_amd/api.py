@@ -41,6 +41,7 @@ ABI_SYMBOLS = {
     "wah_compress_device_ex": (_int, [_vp, _u64, _vp, _u64, _vp, ctypes.c_uint, _vp, _sz, _vp]),
     "wah_compress_device_indexed": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _vp, _sz, _vp]),
     "wah_compress_status": (_int, [_vp, _vp]),
+    "wah_compress_columns_multi_device": (_int, [_int, _vp, _u64, _vp]),
     "wah_decompress_device": (_int, [_vp, _u64, _vp, _u64, _vp, _vp, _sz, _vp]),
     "wah_decompress_device_ex": (_int, [_vp, _u64, _vp, _u64, _vp, ctypes.c_uint, _vp, _sz, _vp]),
     "wah_decompress_scan_device": (_int, [_vp, _u64, _vp, _vp, _sz, _vp]),

@@ -92,6 +92,42 @@ def compress_column_ranges(compressor, flat, lengths, wait=True):
     return stream, compressor.seg_offsets[torch.tensor(first_segment, device=compressor.seg_offsets.device)]
 
 
+def compress_shards_multi_device(wah, shards):
+    """Column shards over several GPUs by ONE call of the C ABI (include/wah.h: wah_compress_columns_multi_device): `shards` =
+    list of (matrix, compressor) with matrix a contiguous [columns, n_words] tensor on the shard's device and compressor a
+    DeviceCompressor(matrix.numel(), device=that device, indexed=True).  One host thread per shard inside the library, each on
+    its own device and stream; nothing is exchanged.  Returns [(stream, column_offsets)] like compress_column_matrix."""
+    import ctypes
+
+    class Shard(ctypes.Structure):
+        _fields_ = [("device", ctypes.c_int), ("n_columns", ctypes.c_uint64), ("d_in", ctypes.c_void_p), ("d_out", ctypes.c_void_p),
+                    ("out_capacity_words", ctypes.c_uint64), ("d_out_words", ctypes.c_void_p), ("d_segment_offsets", ctypes.c_void_p),
+                    ("d_workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+
+    if not shards:
+        return []
+    n = shards[0][0].shape[1]
+    arr = (Shard * len(shards))()
+    for a, (matrix, comp) in zip(arr, shards):
+        if matrix.shape[1] != n or n % SEGMENT_WORDS or not matrix.is_contiguous() or comp.seg_offsets is None:
+            raise ValueError("shards need contiguous [columns, n_words] matrices of one column length (a multiple of 992) and indexed compressors")
+        a.device = matrix.device.index or 0
+        a.n_columns = matrix.shape[0]
+        a.d_in, a.d_out, a.out_capacity_words = matrix.data_ptr(), comp.out.data_ptr(), comp.capacity
+        a.d_out_words, a.d_segment_offsets = comp.count.data_ptr(), comp.seg_offsets.data_ptr()
+        a.d_workspace, a.workspace_bytes = comp.workspace.data_ptr(), comp.ws_bytes
+    import torch
+
+    for matrix, _ in shards:  # (the call's streams are its own: what other streams still write into the inputs must be complete)
+        torch.cuda.synchronize(matrix.device)
+    status = (ctypes.c_int * len(shards))()
+    rc = wah.lib().wah_compress_columns_multi_device(len(shards), ctypes.cast(arr, ctypes.c_void_p), n, ctypes.cast(status, ctypes.c_void_p))
+    if rc != 0:
+        raise wah.WahError(f"wah_compress_columns_multi_device: {rc} (per shard: {list(status)})")
+    segs = n // SEGMENT_WORDS
+    return [(comp.out[: int(comp.count.item())], comp.seg_offsets[:: segs][: matrix.shape[0] + 1]) for matrix, comp in shards]
+
+
 def compress_columns(compressor, columns):
     """Enqueue one compress pass per column on the current stream; returns the list of compressed sizes
     (device tensors, read them after synchronising).  The compressor's output buffer is reused, so callers

@@ -10,6 +10,7 @@
 #include <atomic>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 #include <sys/mman.h>
@@ -565,6 +566,58 @@ int wah_compress_device(const uint32_t *d_in, uint64_t n_words, uint32_t *d_out,
 }
 
 int wah_compress_status(void *d_workspace, void *stream) { return read_status(d_workspace, stream); }
+
+// One host thread per shard: its device made current, a stream of its own, one launch over the shard's column matrix, the
+// status read back.  Nothing crosses between the threads but the join (columns are unrelated bitmaps).
+int wah_compress_columns_multi_device(int n_shards, const wah_column_shard *shards, uint64_t n_words_per_column, int *status) {
+    g_err[0] = 0;
+    if (n_shards < 0 || (n_shards > 0 && !shards)) {
+        set_err("null shard list");
+        return WAH_ERR_ARG;
+    }
+    if (n_words_per_column % WAH_SEGMENT_WORDS != 0) {
+        set_err("columns of a shard must be whole 992-word segments (a fill must not cross into the next column)");
+        return WAH_ERR_ARG;
+    }
+    std::vector<int> rc((size_t)n_shards, WAH_OK);
+    std::vector<std::string> msg((size_t)n_shards);
+    auto work = [&](int i) {
+        const wah_column_shard &sh = shards[i];
+        hipStream_t s = nullptr;
+        if (hipSetDevice(sh.device) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+            rc[i] = WAH_ERR_HIP;
+            msg[i] = "could not make the shard's device current / create its stream";
+            return;
+        }
+        rc[i] = wah_compress_device_indexed(sh.d_in, sh.n_columns * n_words_per_column, sh.d_out, sh.out_capacity_words, sh.d_out_words,
+                                            sh.d_segment_offsets, sh.d_workspace, sh.workspace_bytes, s);
+        if (rc[i] == WAH_OK) rc[i] = wah_compress_status(sh.d_workspace, s); // (synchronises the shard's stream)
+        if (rc[i] != WAH_OK) msg[i] = g_err; // (this thread's own error text)
+        (void)hipStreamDestroy(s);
+    };
+    std::vector<std::thread> threads;
+    threads.reserve((size_t)n_shards);
+    for (int i = 0; i < n_shards; ++i) {
+        try {
+            threads.emplace_back(work, i);
+        } catch (...) { // no thread to be had: this shard on the caller's thread
+            int prev = 0;
+            const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+            work(i);
+            if (have_prev) (void)hipSetDevice(prev);
+        }
+    }
+    for (std::thread &t : threads) t.join();
+    int first = WAH_OK;
+    for (int i = 0; i < n_shards; ++i) {
+        if (status) status[i] = rc[i];
+        if (first == WAH_OK && rc[i] != WAH_OK) {
+            first = rc[i];
+            set_err(msg[i].c_str());
+        }
+    }
+    return first;
+}
 int wah_decompress_status(void *d_workspace, void *stream) { return read_status(d_workspace, stream); }
 
 // clear_first: the workspace is scratch of unknown content (the bitop paths): zero its control block and scan area in

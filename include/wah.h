@@ -161,6 +161,34 @@ int wah_compress_device_indexed(const uint32_t *d_in, uint64_t n_words, uint32_t
 /* Synchronises `stream`, returns WAH_OK or the error a compress launch recorded. */
 int wah_compress_status(void *d_workspace, void *stream);
 
+/* Column shards over several GPUs of a node (the reference is one device, default stream:
+ * compress.cu:129,166).  Columns are independent bitmaps, so there is nothing to exchange: every shard is the column
+ * matrix one device owns (n_columns columns of n_words_per_column words, back to back in that device's memory, every
+ * column a whole number of 992-word segments so that no fill crosses a column), compressed by ONE launch on a stream of
+ * its own by a host thread of its own that makes `device` current -- no collective, no peer access, no RCCL.  All the
+ * other entry points of this header work on the device that is current in the calling thread; this one names its
+ * devices.  Per shard: d_out receives the columns' streams back to back (capacity out_capacity_words;
+ * wah_max_compressed_words(n_columns * n_words_per_column) always suffices), d_out_words their total,
+ * d_segment_offsets (n_columns * n_words_per_column / 992 + 1 entries) the first word of every segment -- column c of
+ * the shard starts at entry c * n_words_per_column / 992 --, d_workspace an initialised workspace of
+ * wah_compress_workspace_bytes(n_columns * n_words_per_column) bytes on that device.  Returns when every shard has
+ * finished: WAH_OK, or the first error (shard order); status[i], if status != NULL, receives shard i's own code.
+ * The launches run on streams of the call's own: inputs and workspaces must be complete when it is made (synchronise
+ * whatever other stream wrote them), and the outputs are complete when it returns.
+ * Several shards may name the same device (they then share it like any two streams). */
+typedef struct {
+    int device;                 /* HIP device ordinal of this shard */
+    uint64_t n_columns;
+    const uint32_t *d_in;       /* n_columns * n_words_per_column words on `device`, 16-byte aligned */
+    uint32_t *d_out;
+    uint64_t out_capacity_words;
+    uint64_t *d_out_words;      /* one uint64 on `device` */
+    uint64_t *d_segment_offsets; /* may be NULL */
+    void *d_workspace;
+    size_t workspace_bytes;
+} wah_column_shard;
+int wah_compress_columns_multi_device(int n_shards, const wah_column_shard *shards, uint64_t n_words_per_column, int *status);
+
 /* d_comp: c_words compressed words, 16-byte aligned.  d_out: room for
  * out_capacity_words decoded words.  d_out_info: two device uint64:
  * [0] = ceil(31*G/32) decoded words, [1] = G groups.

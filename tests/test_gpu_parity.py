@@ -1292,6 +1292,29 @@ def test_column_matrix_one_launch(wah, oracle):
     assert bool(torch.equal(wah.decompress_segments_device(shifted, comp.seg_offsets, matrix.numel(), 2 * segs, segs), matrix[2]))
 
 
+def test_column_shards_by_the_multi_device_entry(wah, oracle):
+    """wah_compress_columns_multi_device: one call, one host thread per shard inside the library, each on the device the
+    shard names and on a stream of its own.  On this box every shard names device 0 (two and three shards sharing it, as
+    two streams would); on a node the same call spreads the shards over its GPUs.  Every column == the oracle's stream."""
+    n = 992 * 500
+    for n_shards in (1, 2, 3):
+        shards, mats = [], []
+        for s in range(n_shards):
+            specs = [wah.columns.column_spec(c, n, seed=70) for c in range(s, 7, n_shards)]  # column c on shard c mod n_shards
+            m = wah.columns.make_column_matrix(wah, specs, "cuda:0")
+            shards.append((m, wah.DeviceCompressor(m.numel(), indexed=True)))
+            mats.append((specs, m))
+        res = wah.columns.compress_shards_multi_device(wah, shards)
+        for (specs, m), (stream, offs) in zip(mats, res):
+            offs = offs.cpu().numpy()
+            assert offs[0] == 0 and offs[-1] == stream.numel() and len(offs) == len(specs) + 1
+            for c in range(len(specs)):
+                assert np.array_equal(_host(stream[offs[c]: offs[c + 1]]), oracle.compress(_host(m[c]))), (n_shards, specs[c].index)
+    # a shard whose columns are not whole segments is refused before anything is launched
+    with pytest.raises(ValueError):
+        wah.columns.compress_shards_multi_device(wah, [(m[:, :991].contiguous(), shards[0][1])])
+
+
 def _indexed_stream(wah, d_in):
     comp = wah.DeviceCompressor(d_in.numel(), indexed=True)
     comp.run(d_in)
