@@ -56,7 +56,10 @@ constexpr uint32_t kCtlDefer = 192;      // the decoders' list of tiles that are
 constexpr uint32_t kDeferSeq = 4;
 constexpr uint32_t kDeferBuckets = 0x80000000u; // in a list entry's parts field: the tile's bucket sums are in tile_buckets
 constexpr uint32_t kBucketSaturated = 0xFFFFFFFFu; // a bucket holding a count above 2^25: the tile is staged whole
-constexpr uint32_t kDeferPartSegs = 32;  // output segments per work item of the list's launch (eight per wave: the chip writes faster the
+#ifndef WAH_DEFER_PART_SEGS
+#define WAH_DEFER_PART_SEGS 32 // (clustered GiB through the list, one box: 16: 0.281 ms, 24: 0.251, 32: 0.2455, 48: 0.253)
+#endif
+constexpr uint32_t kDeferPartSegs = WAH_DEFER_PART_SEGS;  // output segments per work item of the list's launch (eight per wave: the chip writes faster the
                                          // shorter its waves live, tools/expand_want_sweep.sh)
 constexpr uint32_t kCtlWords = 256;      // 1 KiB
 constexpr uint32_t kErrTimeout = 1u;     // a bounded wait expired
