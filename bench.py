@@ -222,6 +222,10 @@ def measure_traffic(args):
     prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if prof is None:
         return None
+    # (already under a profiler -- its preloaded library has initialised the GPU in THIS process: no child may be started from it)
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY")) or \
+            any(k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in os.environ):
+        return None
     raw = collections.defaultdict(dict)
     tmp = tempfile.mkdtemp(prefix="wah_traffic_", dir="/tmp")
     try:
