@@ -272,13 +272,14 @@ class DeviceDecompressor:
 
     ROUTES = {0: "none", 1: "one pass", 2: "two launches", 3: "no wait"}
 
-    def __init__(self, c_words, out_capacity_words, device="cuda:0", no_wait=False, two_launches=False):
+    def __init__(self, c_words, out_capacity_words, device="cuda:0", no_wait=False, two_launches=False, one_pass=False):
         """no_wait: the sums pass by the route in which no workgroup waits for another (include/wah.h: WAH_NO_WAIT);
-        two_launches: scan and expansion as two launches (WAH_TWO_LAUNCHES).  After run(): `route` = the decoder the
-        library launched (wah_last_decode_route)."""
+        two_launches / one_pass: that decoder whatever the capacity suggests (WAH_TWO_LAUNCHES / WAH_ONE_PASS).  After
+        run(): `route` = the decoder the library launched (wah_last_decode_route)."""
         torch = _torch()
         self.no_wait = bool(no_wait)
         self.two_launches = bool(two_launches)
+        self.one_pass = bool(one_pass)
         self.route = "none"
         self.c_words = int(c_words)
         self.capacity = int(out_capacity_words)
@@ -295,7 +296,7 @@ class DeviceDecompressor:
         if c > self.c_words or c > d_comp.numel():
             raise WahError("stream larger than this decompressor was sized for")
         rc = lib().wah_decompress_device_ex(d_comp.data_ptr(), c, self.out.data_ptr(), self.capacity, self.info.data_ptr(),
-                                            (2 if self.no_wait else 0) | (4 if self.two_launches else 0),
+                                            (2 if self.no_wait else 0) | (4 if self.two_launches else 0) | (8 if self.one_pass else 0),
                                             self.workspace.data_ptr(), self.ws_bytes, _stream_ptr(torch, stream))
         self.route = self.ROUTES.get(int(lib().wah_last_decode_route()), "?")
         _check(rc, "wah_decompress_device")

@@ -625,7 +625,7 @@ int wah_decompress_status(void *d_workspace, void *stream) { return read_status(
 static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                          uint64_t *d_out_info, void *d_workspace, size_t workspace_bytes, void *stream, bool do_scan,
                          bool do_expand, bool clear_first = false, uint64_t *host_result = nullptr, bool no_wait = false,
-                         bool two_launches = false) {
+                         int route = 0 /* 0: by the rule below, 1: one pass, 2: two launches */) {
     g_err[0] = 0;
     g_last_route = wah::kRouteNone;
     // WAH_FORCE_FALLBACK=1: every sums pass takes the no-wait route (tests; a GPU shared in ways that starve the scan
@@ -654,17 +654,23 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
     hipStream_t s = static_cast<hipStream_t>(stream);
     char *ws = static_cast<char *>(d_workspace);
     hipError_t e = hipSuccess;
-    // ONE pass over the stream (decode_tile_kernel) whenever the scan and the expansion are asked for together and the stream is
-    // 16-byte aligned -- whatever the stream and whatever the capacity: the kernel decides TILE BY TILE, from the tile's own
-    // words, whether it expands the tile itself (up to about 7 groups per word) or puts it on the list of tiles that the
-    // launch behind it shares out over work items of 32 segments (a highly compressed stream: every tile; a long fill inside
-    // incompressible data: that tile).  WAH_TWO_LAUNCHES (flags) / WAH_DECODE_TWO_PASS=1 (experiment builds): the scan and
-    // the expansion as two launches.
+    // ONE pass over the stream (decode_tile_kernel + the launch over its list) is CORRECT for every 16-byte aligned stream: the
+    // kernel decides tile by tile, from the tile's own words, whether it expands the tile itself (up to about 7 groups per word)
+    // or puts it on the list that the launch behind it shares out over work items.  It is also the FASTER route for streams of
+    // up to 7 groups per word (by 10-13 % against the two launches, which read the stream twice) and as fast from about 32 groups
+    // per word on (every tile on the list: the list's launch is the expand kernel); in between -- 8 to 30 groups per word -- the
+    // two launches win by 15-25 % (tools/decode_density_time.py: the tile kernel is an expensive way to find out that every tile
+    // goes onto the list).  The library cannot look at the stream without a pass over it, so the default goes by what the
+    // CAPACITY allows the stream to be: at most 7 words of output per word of stream, or more than 40 -- one pass; between --
+    // the two launches.  A caller who knows better says so (WAH_ONE_PASS / WAH_TWO_LAUNCHES); decompress(), which has the stream
+    // in host memory, samples it and does.  (WAH_DECODE_TWO_PASS=1, experiment builds: always the two launches.)
     static const bool two_pass_only = [] {
         const char *f = wah::experiment_env("WAH_DECODE_TWO_PASS");
         return f && f[0] == '1';
     }();
-    const bool one_pass = do_scan && do_expand && !no_wait && !two_launches && !two_pass_only && c_words != 0 && aligned16(d_comp);
+    // (7 words of output per word of stream: the tile kernel expands up to 7.5 groups = 7.27 words per word itself)
+    const bool prefer_one_pass = route == 1 || (route == 0 && (out_capacity_words <= 7 * c_words || out_capacity_words > 40 * c_words));
+    const bool one_pass = do_scan && do_expand && !no_wait && prefer_one_pass && !two_pass_only && c_words != 0 && aligned16(d_comp);
     if (do_expand || do_scan) g_last_route = one_pass ? wah::kRouteOnePass : no_wait ? wah::kRouteNoWait : wah::kRouteTwoLaunches;
     if (one_pass) {
         if (clear_first) e = wah::launch_clear(ws, l.base_off, s); // (control block -- with the deferred tiles' counters -- and scan area)
@@ -770,13 +776,13 @@ int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_
 
 int wah_decompress_device_ex(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                              uint64_t *d_out_info, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream) {
-    if (flags & ~(unsigned)(WAH_NO_WAIT | WAH_TWO_LAUNCHES)) {
+    if ((flags & ~(unsigned)(WAH_NO_WAIT | WAH_TWO_LAUNCHES | WAH_ONE_PASS)) || ((flags & WAH_TWO_LAUNCHES) && (flags & WAH_ONE_PASS))) {
         g_err[0] = 0;
-        set_err("unknown flag");
+        set_err("unknown flag, or both WAH_ONE_PASS and WAH_TWO_LAUNCHES");
         return WAH_ERR_ARG;
     }
     return decode_common(d_comp, c_words, d_out, out_capacity_words, d_out_info, d_workspace, workspace_bytes, stream,
-                         true, true, false, nullptr, (flags & WAH_NO_WAIT) != 0, (flags & WAH_TWO_LAUNCHES) != 0);
+                         true, true, false, nullptr, (flags & WAH_NO_WAIT) != 0, (flags & WAH_ONE_PASS) ? 1 : (flags & WAH_TWO_LAUNCHES) ? 2 : 0);
 }
 
 int wah_last_decode_route(void) { return g_last_route; }
@@ -1295,6 +1301,19 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     uint64_t *d_info = reinterpret_cast<uint64_t *>(static_cast<uint32_t *>(d_ws0) + wah::kCtlResult); // beside the error word
     if (c_words && !hip_ok(hipMemcpy(d_comp, comp_host, c_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
         return nullptr;
+    // which decoder: a look at the stream itself, which lies in host memory -- the group counts of up to 65 536 words spread
+    // evenly over it.  One pass up to 7 groups per word; the two launches from there to 128 (tools/report.py, 992 MiB, device
+    // phase: one bit in 2^11 = 32 groups per word 0.248 ms in one pass against 0.223, 2^12 0.223 / 0.210, 2^14 0.209 / 0.203 --
+    // through this boundary the one-pass kernel's longer workgroups show on a stream of a few megabytes); above: the same
+    int route = 1;
+    if (c_words) {
+        uint64_t sampled = 0, sample_groups = 0;
+        const uint64_t stride = c_words > 65536 ? c_words / 65536 : 1;
+        for (uint64_t i = 0; i < c_words; i += stride, ++sampled)
+            sample_groups += (comp_host[i] & wah::kFillZero) ? (comp_host[i] & wah::kCountMask) : 1u;
+        const uint64_t per_word = sample_groups / (sampled ? sampled : 1);
+        route = (per_word <= 7 || per_word >= 128) ? 1 : 2;
+    }
     t_in = hc.stop();
 
     // phase 2: device work (decompress.cu:56-122): size scan, allocate, scan + expand
@@ -1309,7 +1328,7 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     const size_t kept_words = hc.keep && hc.cache.buf[0] ? hc.cache.cap[0] / sizeof(uint32_t) : 0;
     if (c_words && kept_words) {
         rc = decode_common(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(hc.cache.buf[0]), kept_words, d_info, d_ws0,
-                           ws0, nullptr, true, true);
+                           ws0, nullptr, true, true, false, nullptr, false, route);
         hc.mark();
         if (rc == WAH_OK) rc = read_status_packed(d_ws0, hc.cache.pinned, info, 2); // status + sizes in one copy
         if (rc == WAH_OK && test_timeout_hook()) rc = WAH_ERR_TIMEOUT;

@@ -215,15 +215,42 @@ __device__ __forceinline__ u64 *defer_counters_mine(u32 *c) {
 // holds ONE entry per tile whatever the size of the output.  Slot and sum come out of ONE 64-bit atomic, so the entries
 // are SORTED by their sums: work item k of the launch finds its entry by search (expand_list).  c = the launch's counter
 // pair (defer_counters_mine).  false: the list is full (the tile is not on it).
-__device__ __forceinline__ bool dt_defer(u64 *c, u64 *list, u32 capacity, u64 tile, u64 groups, bool buckets = false) {
+__device__ __forceinline__ u32 dt_defer_parts(u64 groups) {
     const u64 segs = groups / kSegGroups + 2ull;
-    const u32 parts = segs >= (u64)kDeferPartSegs * 65536ull ? 65536u : (u32)((segs + kDeferPartSegs - 1ull) / kDeferPartSegs);
-    const u64 old = __hip_atomic_fetch_add(c, 1ull | ((u64)parts << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const u32 slot = (u32)old;
-    if (slot >= capacity) return false; // (also: a counter that did not start at zero must not lead outside the list)
-    list[2ull * slot] = tile | ((u64)(parts | (buckets ? kDeferBuckets : 0u)) << 32);
-    list[2ull * slot + 1] = old >> 32;
+    // (up to one and a half items' worth: ONE item -- an item's fixed costs, finding its entry and staging its words, are a
+    //  quarter of a 16-segment item's life: one bit in 2^9, 35 segments per tile, 0.41 ms in two items per tile)
+    if (segs <= kDeferPartSegs + kDeferPartSegs / 2) return 1u;
+    return segs >= (u64)kDeferPartSegs * 65536ull ? 65536u : (u32)((segs + kDeferPartSegs - 1ull) / kDeferPartSegs);
+}
+// Several tiles at once (those of tile[] whose bit is set in `valid`; the arrays are indexed with constants only: they stay in
+// registers): ONE atomic for all of them -- every appending workgroup's atomic goes to the same address, and a launch is served
+// about 86 of those per microsecond (tools/ticket_rate.hip); a highly compressed stream appends every tile
+template <u32 kMany>
+__device__ __forceinline__ bool dt_defer_many(u64 *c, u64 *list, u32 capacity, u32 valid, const u64 (&tile)[kMany], const u64 (&groups)[kMany], bool buckets) {
+    if (valid == 0u) return true;
+    u32 parts[kMany], sum = 0;
+#pragma unroll
+    for (u32 i = 0; i < kMany; ++i) {
+        parts[i] = (valid >> i) & 1u ? dt_defer_parts(groups[i]) : 0u;
+        sum += parts[i];
+    }
+    const u32 n = (u32)__builtin_popcount(valid);
+    const u64 old = __hip_atomic_fetch_add(c, (u64)n | ((u64)sum << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u32 slot = (u32)old, before = (u32)(old >> 32);
+    if (slot >= capacity || capacity - slot < n) return false; // (also: a counter that did not start at zero must not lead outside the list)
+#pragma unroll
+    for (u32 i = 0; i < kMany; ++i)
+        if ((valid >> i) & 1u) {
+            list[2ull * slot] = tile[i] | ((u64)(parts[i] | (buckets ? kDeferBuckets : 0u)) << 32);
+            list[2ull * slot + 1] = before;
+            ++slot;
+            before += parts[i];
+        }
     return true;
+}
+__device__ __forceinline__ bool dt_defer(u64 *c, u64 *list, u32 capacity, u64 tile, u64 groups, bool buckets = false) {
+    const u64 t[1] = {tile}, g[1] = {groups};
+    return dt_defer_many<1>(c, list, capacity, 1u, t, g, buckets);
 }
 
 // kWaveTiles: expand tiles a wavefront sums one after the other (long streams: 4, so that ticket, barrier and scan are
@@ -576,15 +603,27 @@ __device__ __forceinline__ void expand_segment_with_empties(const ExpandArgs &a,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// ---- a whole segment that lies inside ONE fill word (the inside of a long run: classic WAH, mostly empty bitmaps): 992 equal
+// words -- no flags, no ranks, no gathers: four 16-byte stores per lane, the store shape of a fill kernel (248 pieces of 16 bytes;
+// the descriptor drops what lies behind them and behind the capacity)
+__device__ __forceinline__ void store_constant_segment(u32 *out, u64 seg_w0, u32 seg_words, u32 fill_word, u32 lane) {
+    const u32 v = (fill_word & 0x40000000u) ? 0xFFFFFFFFu : 0u;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(out + seg_w0, seg_words * 4u);
+    const u32x4 q = {v, v, v, v};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, lane * 16u, 1024 * i, 0);
+}
+
 // ---- one output segment, fast version: the tile expands to fewer than 2^31 groups, so every position relative to the
 // segment start fits a signed 32-bit integer; bookkeeping stays in vector registers (see compress_kernel) ----------
 
 // One batch of the mark phase: the next 128 words, two per lane.  `rel` = where the batch starts, seen from the
 // segment start (<= 0 at first).  Flags the group at which every contributing word starts (clipped at the segment
 // start).  kFirst: returns the tile-local index of the first contributing word.
+// kFirst also: `whole` = the word that covers the WHOLE segment [0, nvalid), if one does (a fill: nonzero), else 0.
 template <bool kLocal, bool kFirst>
 __device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, u32 *s_words, unsigned char *flag, u64 tile_w0,
-                                          u32 left_in_stream, u32 nvalid, u32 lane, int &rel, u32 &wi) {
+                                          u32 left_in_stream, u32 nvalid, u32 lane, int &rel, u32 &wi, u32 *whole = nullptr) {
     const u32 i0 = wi + 2u * lane;
     u32 w0, w1;
     if (kLocal) {
@@ -617,6 +656,11 @@ __device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, u32 *s_words, uns
         const u64 m0 = __ballot(c0), m1 = __ballot(c1);
         const u32 l = (u32)__ffsll((long long)(m0 | m1)) - 1u;
         first = wi + 2u * l + (((m0 >> l) & 1ull) ? 0u : 1u);
+        if (whole) { // (the first contributing word is the only candidate)
+            const bool w0_all = c0 && lo0 <= 0 && lo1 >= (int)nvalid, w1_all = c1 && lo1 <= 0 && hi1 >= (int)nvalid;
+            const u64 ma = __ballot(w0_all || w1_all);
+            *whole = ma ? (u32)__builtin_amdgcn_readlane((int)(w0_all ? w0 : w1), __builtin_ctzll(ma)) : 0u;
+        }
     }
     rel += (int)(u32)__builtin_amdgcn_readlane((int)incl, 63);
     wi += 128u;
@@ -638,8 +682,14 @@ __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, u32 *s_
     u32 wi = bucket * 64u;
     constexpr u32 kLastLocal = (u32)kScanTileWords - 128u; // batches starting up to here come out of the LDS tile
     // the word that covers the segment's first group is in the first batch (that is how the bucket was chosen)
-    const u32 first_word = wi <= kLastLocal ? mark_pairs<true, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi)
-                                            : mark_pairs<false, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi);
+    u32 whole = 0;
+    const u32 first_word = wi <= kLastLocal ? mark_pairs<true, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi, &whole)
+                                            : mark_pairs<false, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi, &whole);
+    if (whole != 0u && nvalid == kSegGroups && (seg + 1) * kSegWords <= out_words) { // (wave-uniform) the inside of a long fill
+        const u64 seg_w0 = seg * kSegWords;
+        store_constant_segment(a.out, seg_w0, kSegWords, whole, lane);
+        return;
+    }
     while (rel < (int)nvalid && wi <= kLastLocal)
         (void)mark_pairs<true, false>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi);
     while (rel < (int)nvalid && wi < left_in_stream)
@@ -655,8 +705,8 @@ __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, u32 *s_
 
 // one expand tile (4096 words of the stream): the output segments that start inside it (every parts-th batch of them).
 // (The LDS arrays are this function's own: decode_expand_kernel and decode_expand_list_kernel each inline it once.)
-// kContiguous (the list's launch): part p = the kDeferPartSegs CONSECUTIVE segments p of the tile, not every parts-th group of
-// four -- and with `buckets` (the tile's 64 sums of group counts per 64 words, left by decode_tile_kernel) the workgroup stages
+// kContiguous (the list's launch): part p = the p-th of `parts` equal shares of CONSECUTIVE segments of the tile, not every parts-th
+// group of four -- and with `buckets` (the tile's 64 sums of group counts per 64 words, left by decode_tile_kernel) the workgroup stages
 // only the words those segments need instead of the whole tile: a tile of a highly compressed stream is shared by eight or
 // more work items, each of which used to read all 16 KiB of it and count them (a quarter of the item's life, 1.13 x the
 // algorithmic traffic on the clustered GiB).
@@ -667,8 +717,13 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     __shared__ u32 s_coarse32[kCoarse + 1]; // the same in 32 bits (valid when the tile total is below 2^31)
     __shared__ u64 s_wave_sum[kExpandWaves];
     __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][kFlagBytes]; // 1: a word starts at this group
-    const u32 lane = lane_id();
-    const u32 wave = wave_id();
+    // (the thread's number through an opaque move: inside the list launch's loop over work items everything derived from it --
+    //  lane constants, LDS addresses -- would otherwise be made once in front of the loop and kept in registers across it: 123
+    //  registers against the 70 of the routine on its own)
+    u32 tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const u32 lane = tid & 63u;
+    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
 #ifdef WAH_DIAG
     const u64 dg_start = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -679,7 +734,7 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     const u64 all_tiles = (a.c_words + kScanTileWords - 1) / kScanTileWords;
     const bool has_empties = ((a.tile_flags[tile] | ((u64)tile + 1 < all_tiles ? a.tile_flags[tile + 1] : 0)) & 1) != 0;
     if (out_words > a.out_capacity) {
-        if (threadIdx.x == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
+        if (tid == 0) atomicOr(a.ctrl + kCtlError, kErrCapacity);
         return;
     }
 
@@ -707,8 +762,9 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
         const u32 total_p = uniform32(s_coarse32[kCoarse]); // (< 2^31: no bucket is saturated)
         const u64 kb = (base_p + kSegGroups - 1) / kSegGroups;
         const u64 ke = (base_p + total_p + kSegGroups - 1) / kSegGroups;
-        const u64 s0 = kb + (u64)kDeferPartSegs * part;
-        const u64 s1 = s0 + kDeferPartSegs < ke ? s0 + kDeferPartSegs : ke;
+        const u64 per = (ke - kb + parts - 1) / parts; // the tile's segments in `parts` EQUAL shares (see below)
+        const u64 s0 = kb + per * part;
+        const u64 s1 = s0 + per < ke ? s0 + per : ke;
         if (s0 >= s1) return; // (wave-uniform; dt_defer's parts are an upper bound)
         const u32 t0 = (u32)(s0 * kSegGroups - base_p);                                   // first group needed (< total)
         const u64 t1_64 = s1 * kSegGroups - base_p;
@@ -721,9 +777,9 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
         if (a.aligned16 && tile_w0 + kScanTileWords <= a.c_words) {
             const uint4 *src = reinterpret_cast<const uint4 *>(a.comp + tile_w0);
             uint4 *dst = reinterpret_cast<uint4 *>(s_words);
-            for (u32 i = w_lo / 4u + threadIdx.x; i < w_hi / 4u; i += kExpandThreads) dst[i] = src[i];
+            for (u32 i = w_lo / 4u + tid; i < w_hi / 4u; i += kExpandThreads) dst[i] = src[i];
         } else {
-            for (u32 i = w_lo + threadIdx.x; i < w_hi; i += kExpandThreads) s_words[i] = tile_w0 + i < a.c_words ? a.comp[tile_w0 + i] : 0x80000000u;
+            for (u32 i = w_lo + tid; i < w_hi; i += kExpandThreads) s_words[i] = tile_w0 + i < a.c_words ? a.comp[tile_w0 + i] : 0x80000000u;
         }
         __syncthreads();
     } else {
@@ -735,18 +791,18 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
         uint4 v[kVec];
 #pragma unroll
         // (default cache policy: nontemporal loads here made the round trip slower, 1469 -> 1423 GB/s on the sparse GiB)
-        for (int k = 0; k < kVec; ++k) v[k] = src[k * kExpandThreads + (int)threadIdx.x]; // coalesced 16-byte loads
+        for (int k = 0; k < kVec; ++k) v[k] = src[k * kExpandThreads + (int)tid]; // coalesced 16-byte loads
 #pragma unroll
-        for (int k = 0; k < kVec; ++k) dst[k * kExpandThreads + (int)threadIdx.x] = v[k];
+        for (int k = 0; k < kVec; ++k) dst[k * kExpandThreads + (int)tid] = v[k];
     } else {
-        for (u32 i = threadIdx.x; i < (u32)kScanTileWords; i += kExpandThreads)
+        for (u32 i = tid; i < (u32)kScanTileWords; i += kExpandThreads)
             s_words[i] = tile_w0 + i < a.c_words ? a.comp[tile_w0 + i] : 0x80000000u; // past the end: empty fill
     }
     __syncthreads();
     // every thread sums the counts of its own 16 consecutive words
     u64 mine = 0;
     {
-        const uint4 *my = reinterpret_cast<const uint4 *>(s_words + threadIdx.x * kExpandWordsPerThread);
+        const uint4 *my = reinterpret_cast<const uint4 *>(s_words + tid * kExpandWordsPerThread);
 #pragma unroll
         for (int k = 0; k < kVec; ++k) {
             const uint4 q = my[k];
@@ -759,11 +815,11 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     u64 excl = incl - mine;
     for (u32 k = 0; k < wave; ++k) excl += s_wave_sum[k];
     constexpr u32 kThreadsPer64 = 64 / kExpandWordsPerThread;
-    if (threadIdx.x % kThreadsPer64 == 0) { // first thread of each 64 words
-        s_coarse[threadIdx.x / kThreadsPer64] = excl;
-        s_coarse32[threadIdx.x / kThreadsPer64] = (u32)excl;
+    if (tid % kThreadsPer64 == 0) { // first thread of each 64 words
+        s_coarse[tid / kThreadsPer64] = excl;
+        s_coarse32[tid / kThreadsPer64] = (u32)excl;
     }
-    if (threadIdx.x == kExpandThreads - 1) {
+    if (tid == kExpandThreads - 1) {
         s_coarse[kCoarse] = excl + mine;
         s_coarse32[kCoarse] = (u32)(excl + mine);
     }
@@ -779,6 +835,11 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     const u64 n_seg = (groups + kSegGroups - 1) / kSegGroups;
     const u64 k_begin = (base + kSegGroups - 1) / kSegGroups;
     u64 k_end = (base + total + kSegGroups - 1) / kSegGroups;
+    // kContiguous: the segments that start in the tile in `parts` EQUAL shares of consecutive segments (dt_defer's parts = one per
+    // kDeferPartSegs segments, rounded up: 35 segments are two shares of 18 and 17, not 32 and 3 -- with unequal shares, and the
+    // launch's workgroups taking items w, w + G, ..., every other workgroup got the long ones: 0.59 ms where the two launches
+    // take 0.28, tools/decode_density_time.py, one bit in 2^9)
+    const u64 per = kContiguous ? (k_end - k_begin + parts - 1) / parts : 0;
     if (k_end > n_seg) k_end = n_seg;
 
     if (has_empties) {
@@ -787,8 +848,8 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
         // hold its 1024-entry index map
         static_assert(sizeof(s_flag) >= kSegGroups * sizeof(u32), "index map must fit the flag areas");
         if (wave == 0) {
-            const u64 e_first = kContiguous ? k_begin + (u64)kDeferPartSegs * part : k_begin + part;
-            const u64 e_last = kContiguous && e_first + kDeferPartSegs < k_end ? e_first + kDeferPartSegs : k_end;
+            const u64 e_first = kContiguous ? k_begin + per * part : k_begin + part;
+            const u64 e_last = kContiguous && e_first + per < k_end ? e_first + per : k_end;
             for (u64 seg = e_first; seg < e_last; seg += kContiguous ? 1u : parts)
                 expand_segment_with_empties(a, s_words, s_coarse, reinterpret_cast<u32 *>(&s_flag[0][0]), tile_w0, base, groups,
                                             out_words, seg, lane);
@@ -797,8 +858,8 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     }
     unsigned char *flag = s_flag[wave];
     const bool tame = total < (1ull << 31); // wave-uniform: positions inside this tile fit 32 bits
-    const u64 seg_first = kContiguous ? k_begin + (u64)kDeferPartSegs * part + wave : k_begin + wave + (u64)kExpandWaves * part;
-    const u64 seg_last = kContiguous && k_begin + (u64)kDeferPartSegs * (part + 1u) < k_end ? k_begin + (u64)kDeferPartSegs * (part + 1u) : k_end;
+    const u64 seg_first = kContiguous ? k_begin + per * part + wave : k_begin + wave + (u64)kExpandWaves * part;
+    const u64 seg_last = kContiguous && k_begin + per * (part + 1u) < k_end ? k_begin + per * (part + 1u) : k_end;
     for (u64 seg = seg_first; seg < seg_last; seg += kContiguous ? (u64)kExpandWaves : (u64)kExpandWaves * parts) {
         if (tame) {
             const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
@@ -883,7 +944,7 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
 }
 
 #ifndef WAH_LIST_MINW
-#define WAH_LIST_MINW 5 // (inlined inside the loop over work items the tile routine wants 123 registers; capped at 95 it spills nothing: five waves per SIMD)
+#define WAH_LIST_MINW 6 // (80 registers, nothing spilled -- with the thread's number made opaque inside the tile routine; without: 123)
 #endif
 // the expand tiles decode_tile_kernel left to this route (giant fills, fill words of count 0: foreign streams), out of its
 // list; normally the list is empty and the launch ends at once.
@@ -929,6 +990,13 @@ __device__ __forceinline__ void seg_store(const SegStore &st, int s, u32 grp) {
 // segment first_segment + k of the bitmap, its words in x0/x1 -> a.out + 992 k
 __device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const SegRange &rg, const u32 (&x0)[kSegBatches],
                                            const u32 (&x1)[kSegBatches], unsigned char *flag, u32 *words, u32 lane) {
+    // a segment that is ONE fill word of all its 1024 groups (mostly empty bitmaps: most of their segments): 992 equal words
+    const u32 only = (u32)__builtin_amdgcn_readfirstlane((int)x0[0]);
+    if (rg.cnt == 1u && !rg.bad && rg.nvalid == kSegGroups && only >= kFillZero && (only & kCountMask) == kSegGroups &&
+        (a.first_segment + k + 1) * kSegWords <= a.out_words) {
+        store_constant_segment(a.out, k * kSegWords, kSegWords, only, lane);
+        return;
+    }
     if (!seg_mark(rg, x0, x1, flag, words, lane)) {
         if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
         return;

@@ -192,12 +192,18 @@ int wah_compress_columns_multi_device(int n_shards, const wah_column_shard *shar
 /* d_comp: c_words compressed words, 16-byte aligned.  d_out: room for
  * out_capacity_words decoded words.  d_out_info: two device uint64:
  * [0] = ceil(31*G/32) decoded words, [1] = G groups.
- * ONE pass over the stream, whatever the stream and whatever the capacity: the decoder decides tile by tile (8192
- * words), from the tile's own words, whether the workgroup that holds it expands it (up to about 7 groups per word) or
- * puts it on a list that a second launch shares out in work items of 32 output segments (a highly compressed stream:
- * every tile; a long fill inside incompressible data: that tile).  The capacity does not choose the route.  (A stream
- * that is only 4-byte aligned, and WAH_TWO_LAUNCHES / WAH_NO_WAIT below: a scan of the stream + an expansion pass, as
- * _scan_device + _expand_device.)  wah_last_decode_route() says which one the calling thread's last call launched.
+ * Two decoders, the same words out of both.  ONE PASS over the stream (decode_tile_kernel): it decides tile by tile
+ * (8192 words), from the tile's own words, whether the workgroup that holds the tile expands it (up to about 7 groups
+ * per word) or puts it on a list that a second launch shares out in work items of about 32 output segments (a highly
+ * compressed stream: every tile; a long fill inside incompressible data: that tile) -- correct for every stream,
+ * the faster one up to about 7 groups per word (the stream is read once) and as fast from about 32 on.  TWO LAUNCHES
+ * (a scan of the stream + an expansion pass, as _scan_device + _expand_device): 15-25 % faster between 8 and 30 groups
+ * per word, where the one pass finds out tile by tile that everything goes onto its list.  Without a pass over the
+ * stream the library cannot know which it holds, so the DEFAULT goes by what out_capacity_words allows it to be: at most
+ * 7 words of output per word of stream, or more than 40: one pass; between: two launches.  A caller who knows the
+ * stream passes WAH_ONE_PASS or WAH_TWO_LAUNCHES (wah_decompress_device_ex); decompress(), which has the stream in
+ * host memory, samples it.  A stream that is only 4-byte aligned and WAH_NO_WAIT: always the two launches.
+ * wah_last_decode_route() says which one the calling thread's last call launched.
  * On ANY status other than WAH_OK the content of d_out is undefined: on WAH_ERR_CAPACITY the one-pass decoder has
  * written the part that fits (it learns the size while it writes; nothing is ever written behind out_capacity_words),
  * the two-launch routes nothing; on WAH_ERR_TIMEOUT / WAH_ERR_STREAM segments may have been written at positions
@@ -214,8 +220,10 @@ int wah_decompress_device(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_
  * of the workspace's earlier content; before the scan route is used again after a WAH_ERR_TIMEOUT the workspace must be
  * initialised again (wah_workspace_init_device). */
 /* WAH_TWO_LAUNCHES: the scan of the stream (decode_sums_kernel) and the expansion (decode_expand_kernel) as two launches
- * with waits, as _scan_device + _expand_device: the stream is read twice. */
+ * with waits, as _scan_device + _expand_device: the stream is read twice.  WAH_ONE_PASS: decode_tile_kernel + the launch
+ * over its list, whatever the capacity suggests.  (Not both.) */
 #define WAH_TWO_LAUNCHES 4u
+#define WAH_ONE_PASS 8u
 int wah_decompress_device_ex(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_out, uint64_t out_capacity_words,
                              uint64_t *d_out_info, unsigned flags, void *d_workspace, size_t workspace_bytes, void *stream);
 

@@ -797,13 +797,14 @@ def test_decode_mostly_empty_bitmap_with_dense_islands(wah, oracle):
 
 
 def test_decoder_route_is_a_property_of_the_stream(wah, oracle):
-    """wah_decompress_device decodes in ONE pass over the stream whatever the stream and whatever capacity the caller names
-    (include/wah.h): decode_tile_kernel decides tile by tile whether it expands a tile itself or puts it on the list the launch
-    behind it shares out.  An incompressible stream with 64 times the capacity it needs, a highly compressed one with exactly
-    what it needs, a mix of both: the library reports the one-pass route (wah_last_decode_route) and the words are the
-    oracle's.  The other routes on request or by necessity: WAH_TWO_LAUNCHES, WAH_NO_WAIT, a stream that is only 4-byte
-    aligned.  And what a capacity that is too small leaves behind, route by route (d_out is undefined then, include/wah.h:
-    pinned here so that a change is seen)."""
+    """The one-pass decoder is correct for EVERY stream: decode_tile_kernel decides tile by tile whether it expands a tile
+    itself or puts it on the list the launch behind it shares out (include/wah.h).  An incompressible stream with 64 times the
+    capacity it needs, a highly compressed one with exactly what it needs, a mix of both: the default takes the one pass
+    (wah_last_decode_route) and the words are the oracle's.  Where the capacity allows 7 to 40 words of output per word of
+    stream the default is the two launches (faster for streams of that kind), and WAH_ONE_PASS / WAH_TWO_LAUNCHES overrule
+    it either way with the same words.  The other routes by necessity: WAH_NO_WAIT, a stream that is only 4-byte aligned.
+    And what a capacity that is too small leaves behind, route by route (d_out is undefined then, include/wah.h: pinned here
+    so that a change is seen)."""
     import torch
 
     n = 992 * 2600
@@ -811,6 +812,19 @@ def test_decoder_route_is_a_property_of_the_stream(wah, oracle):
     clustered = oracle.gen_clustered(n, 4)
     mixed = dense.copy()
     mixed[992 * 700: 992 * 1900] = clustered[992 * 700: 992 * 1900]
+    middling = oracle.gen_uniform(n, 5, 2.0 ** -9)  # about 9 groups per word
+    st = oracle.compress(middling)
+    want = oracle.decompress(st)
+    for kw, route in (({}, "two launches"), ({"one_pass": True}, "one pass"), ({"two_launches": True}, "two launches")):
+        dec = wah.DeviceDecompressor(len(st), n + 1, **kw)
+        dec.run(_dev(st))
+        assert dec.route == route, (kw, dec.route)
+        assert np.array_equal(_host(dec.result()), want), kw
+    dec = wah.DeviceDecompressor(len(st), 64 * n)  # ... and with a capacity that says nothing, the decoder that is right for anything
+    dec.run(_dev(st))
+    assert dec.route == "one pass" and np.array_equal(_host(dec.result()), want)
+    with pytest.raises(wah.WahError):
+        wah.DeviceDecompressor(len(st), n + 1, one_pass=True, two_launches=True).run(_dev(st))
     for name, x, cap in (("dense, 64 x the capacity", dense, 64 * n), ("clustered", clustered, n + 1), ("mixed", mixed, 3 * n)):
         st = oracle.compress(x)
         want = oracle.decompress(st)
@@ -871,7 +885,7 @@ def test_decode_listed_tiles_stage_only_their_words(wah, oracle):
         want = oracle.decompress(stream)
         assert np.array_equal(want[: x.size], x), name
         for cap in (want.size, want.size + 1, 5 * want.size):
-            dec = wah.DeviceDecompressor(len(stream), cap)
+            dec = wah.DeviceDecompressor(len(stream), cap, one_pass=True)
             for _ in range(2):
                 dec.run(_dev(stream))
                 assert dec.route == "one pass"
