@@ -1299,12 +1299,11 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     // zeroed once; from then on the sums kernel keeps it up itself (launch epochs)
     if (fresh_ws && wah_workspace_init_device(d_ws0, ws0, nullptr) != WAH_OK) return nullptr;
     uint64_t *d_info = reinterpret_cast<uint64_t *>(static_cast<uint32_t *>(d_ws0) + wah::kCtlResult); // beside the error word
-    if (c_words && !hip_ok(hipMemcpy(d_comp, comp_host, c_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
-        return nullptr;
     // which decoder: a look at the stream itself, which lies in host memory -- the group counts of up to 65 536 words spread
     // evenly over it.  One pass up to 7 groups per word; the two launches from there to 128 (tools/report.py, 992 MiB, device
     // phase: one bit in 2^11 = 32 groups per word 0.248 ms in one pass against 0.223, 2^12 0.223 / 0.210, 2^14 0.209 / 0.203 --
-    // through this boundary the one-pass kernel's longer workgroups show on a stream of a few megabytes); above: the same
+    // through this boundary the one-pass kernel's longer workgroups show on a stream of a few megabytes); above: the same.
+    // (BEFORE the copy: a device left idle for the millisecond this takes starts its next kernel slower)
     int route = 1;
     if (c_words) {
         uint64_t sampled = 0, sample_groups = 0;
@@ -1314,6 +1313,8 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
         const uint64_t per_word = sample_groups / (sampled ? sampled : 1);
         route = (per_word <= 7 || per_word >= 128) ? 1 : 2;
     }
+    if (c_words && !hip_ok(hipMemcpy(d_comp, comp_host, c_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
+        return nullptr;
     t_in = hc.stop();
 
     // phase 2: device work (decompress.cu:56-122): size scan, allocate, scan + expand
