@@ -657,10 +657,11 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
     // ONE pass over the stream (decode_tile_kernel + the launch over its list) is CORRECT for every 16-byte aligned stream: the
     // kernel decides tile by tile, from the tile's own words, whether it expands the tile itself (up to about 7 groups per word)
     // or puts it on the list that the launch behind it shares out over work items.  It is also the FASTER route for streams of
-    // up to 7 groups per word (by 10-13 % against the two launches, which read the stream twice) and as fast from about 32 groups
-    // per word on (every tile on the list: the list's launch is the expand kernel); in between -- 8 to 30 groups per word -- the
-    // two launches win by 15-25 % (tools/decode_density_time.py: the tile kernel is an expensive way to find out that every tile
-    // goes onto the list).  The library cannot look at the stream without a pass over it, so the default goes by what the
+    // up to 7 groups per word (by 13-19 % against the two launches, which read the stream twice), as fast within 1.5 % from about
+    // 32 groups per word on (every tile on the list: the list's launch is the expand kernel) and 3-6 % faster from about 200; in
+    // between -- 8 to 30 groups per word -- the two launches win by about 20 % (tools/decode_density_time.py, 992 MiB, one bit in
+    // 2^9: 0.343 ms against 0.282, 2^10: 0.315 / 0.246 -- a stream of 60-130 MB is 2000-4000 workgroups of the tile kernel, whose
+    // tickets and list entries come out of one address each at 86 per microsecond: 98 us where the sums kernel takes 41).  The library cannot look at the stream without a pass over it, so the default goes by what the
     // CAPACITY allows the stream to be: at most 7 words of output per word of stream, or more than 40 -- one pass; between --
     // the two launches.  A caller who knows better says so (WAH_ONE_PASS / WAH_TWO_LAUNCHES); decompress(), which has the stream
     // in host memory, samples it and does.  (WAH_DECODE_TWO_PASS=1, experiment builds: always the two launches.)

@@ -741,7 +741,9 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     // ---- with bucket sums: the coarse prefix is their scan, and only the words of this part's segments are staged ---------
     __shared__ u32 s_partial; // 1: the coarse prefix is made, the part's words are staged
     bool partial = false;
+    u64 base_ahead = 0; // (asked for in front of the bucket scan and its barrier, not behind them)
     if (kContiguous && buckets != nullptr) {
+        base_ahead = a.tile_base[tile];
         if (wave == 0) {
             const u32 v = buckets[lane];
             const bool sat = __any(v == kBucketSaturated);
@@ -758,7 +760,7 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
         partial = uniform32(s_partial) != 0u;
     }
     if (partial) {
-        const u64 base_p = a.tile_base[tile];
+        const u64 base_p = base_ahead;
         const u32 total_p = uniform32(s_coarse32[kCoarse]); // (< 2^31: no bucket is saturated)
         const u64 kb = (base_p + kSegGroups - 1) / kSegGroups;
         const u64 ke = (base_p + total_p + kSegGroups - 1) / kSegGroups;
@@ -895,33 +897,64 @@ __device__ __forceinline__ void expand_list(const ExpandArgs &a, const u64 *list
     const u64 n_et = (a.c_words + kScanTileWords - 1) / kScanTileWords;
     // the counter pair of the launch that has just ended (count[kDeferSeq] = launches so far; wah_internal.hpp, kCtlDefer): read
     // only -- the NEXT launch that may append zeroes it
-    const u32 seq = uniform32(__hip_atomic_load(count + kDeferSeq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const u64 pair = __hip_atomic_load(reinterpret_cast<const u64 *>(count) + ((seq - 1u) & 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u32 n = uniform32((u32)pair);
-    const u32 items = uniform32((u32)(pair >> 32)); // work items = the sum of the entries' parts
-    if (n > capacity) n = capacity; // (whatever the counter holds: every access stays inside the list and the stream)
+    // (both pairs and the launch count in ONE round of loads -- three lanes -- not one behind the other: every load in front of
+    //  an item's first word is a microsecond of its life when the chip is busy)
     const u32 lane = lane_id();
-    // Work item k (k = w, w + G, ...) belongs to the LAST entry whose sum of earlier parts is <= k: the entries are sorted by
-    // that sum (dt_defer), so a 64-ary search finds it in two or three rounds of one load each -- every wave for itself, no
-    // barrier (the values are the same in all of them).
+    const u64 cv = lane < 3u ? __hip_atomic_load(reinterpret_cast<const u64 *>(count) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    static_assert(kDeferSeq == 4u, "the launch count is the low half of the third 64-bit word");
+    const u32 seq = (u32)__builtin_amdgcn_readlane((int)(u32)cv, 2);
+    const u32 which = (seq - 1u) & 1u;
+    u32 n = (u32)__builtin_amdgcn_readlane((int)(u32)cv, which);
+    const u32 items = (u32)__builtin_amdgcn_readlane((int)(u32)(cv >> 32), which); // work items = the sum of the entries' parts
+    if (n > capacity) n = capacity; // (whatever the counter holds: every access stays inside the list and the stream)
+    // Work item k (k = w, w + G, ...) belongs to the LAST entry whose sum of earlier parts is <= k; the entries are sorted by
+    // that sum (dt_defer).  FIRST a guess: tiles of one stream are much alike, so the entry lies near k * entries / items (all
+    // tiles in one part each -- one bit in 2^9: exactly there) -- the 64 entries around the guess in one round of 16-byte loads,
+    // found when the window holds an entry <= k in front of one > k (or of the list's end).  Otherwise a 64-ary search, two or
+    // three rounds of one load each.  Every wave for itself, no barrier (the values are the same in all of them).
     for (u32 k = w; k < items; k += G) {
-        u32 lo = 0, len = n; // the entry lies in [lo, lo + len)
-        while (len > 64u) {
-            const u32 stride = (len + 63u) / 64u;
-            const u32 i = lo + lane * stride;
-            const bool le = lane * stride < len && (u32)list[2ull * i + 1] <= k;
-            const u32 below = (u32)__popcll(__ballot(le)); // (lane 0's entry is always <= k: the one found in the round before)
-            const u32 at = (below ? below - 1u : 0u) * stride;
-            lo += at;
-            len = len - at < stride ? len - at : stride;
+        u32 e = 0xFFFFFFFFu;
+        u64 entry = 0;
+        u32 before = 0;
+        {
+            const u32 guess = (u32)(((u64)k * n) / items);
+            u32 w_lo = guess > 32u ? guess - 32u : 0u;
+            if (w_lo + 64u > n) w_lo = n > 64u ? n - 64u : 0u;
+            const u32 w_len = n - w_lo < 64u ? n - w_lo : 64u;
+            u64 ev = 0, bv = ~0ull;
+            if (lane < w_len) {
+                const ulong2 q = *reinterpret_cast<const ulong2 *>(list + 2ull * (w_lo + lane));
+                ev = q.x, bv = q.y;
+            }
+            const u32 below = (u32)__popcll(__ballot(lane < w_len && (u32)bv <= k));
+            if (below != 0u && (below < w_len || w_lo + w_len == n)) {
+                e = w_lo + below - 1u;
+                entry = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(ev >> 32), below - 1u) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)ev, below - 1u);
+                before = (u32)__builtin_amdgcn_readlane((int)(u32)bv, below - 1u);
+            }
         }
-        const bool le = lane < len && (u32)list[2ull * (lo + lane) + 1] <= k;
-        const u32 below = (u32)__popcll(__ballot(le));
-        if (below == 0u) continue; // (a list that is not what dt_defer wrote)
-        const u32 e = uniform32(lo + below - 1u);
-        const u64 entry = list[2ull * e];
-        const u32 tile = uniform32((u32)entry), parts = uniform32((u32)(entry >> 32)) & ~kDeferBuckets, part = k - uniform32((u32)list[2ull * e + 1]);
-        const bool buckets = (uniform32((u32)(entry >> 32)) & kDeferBuckets) != 0u && a.tile_buckets != nullptr;
+        if (e == 0xFFFFFFFFu) {
+            u32 lo = 0, len = n; // the entry lies in [lo, lo + len)
+            while (len > 64u) {
+                const u32 stride = (len + 63u) / 64u;
+                const u32 i = lo + lane * stride;
+                const bool le = lane * stride < len && (u32)list[2ull * i + 1] <= k;
+                const u32 below = (u32)__popcll(__ballot(le)); // (lane 0's entry is always <= k: the one found in the round before)
+                const u32 at = (below ? below - 1u : 0u) * stride;
+                lo += at;
+                len = len - at < stride ? len - at : stride;
+            }
+            const bool le = lane < len && (u32)list[2ull * (lo + lane) + 1] <= k;
+            const u32 below = (u32)__popcll(__ballot(le));
+            if (below == 0u) continue; // (a list that is not what dt_defer wrote)
+            e = uniform32(lo + below - 1u);
+            entry = uniform64(list[2ull * e]);
+            before = uniform32((u32)list[2ull * e + 1]);
+        }
+        const u32 tile = (u32)entry, parts = (u32)(entry >> 32) & ~kDeferBuckets, part = k - before;
+        // (a tile in ONE part needs all its words: staged whole, at once, as decode_expand_kernel does -- the bucket sums would be
+        //  two more rounds of loads in front of the first word)
+        const bool buckets = ((u32)(entry >> 32) & kDeferBuckets) != 0u && a.tile_buckets != nullptr && parts > 1u;
         if (tile >= n_et || parts == 0u || parts > 65536u || part >= parts) continue;
         if (listed_tile_is_regular(a, tile, regular_parts)) continue;
         if (k != w) __syncthreads(); // the LDS image goes to the next tile
@@ -1226,6 +1259,9 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *de
         hipLaunchKernelGGL(decode_tile_kernel<1>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t);
     else
         hipLaunchKernelGGL(decode_tile_kernel<2>, dim3(t.n_wg_tiles), dim3(kDtWaves * 64), 0, s, t);
+#ifdef WAH_DIAG
+    if (std::getenv("WAH_DIAG_NO_LIST")) return hipGetLastError(); // (the time line in the output's head survives: tools/decode_tile_timeline.py)
+#endif
     ExpandArgs x = xa;
     x.parts = 1;
     x.defer_list = nullptr; // (the list is this launch's own argument)

@@ -196,13 +196,14 @@ int wah_compress_columns_multi_device(int n_shards, const wah_column_shard *shar
  * (8192 words), from the tile's own words, whether the workgroup that holds the tile expands it (up to about 7 groups
  * per word) or puts it on a list that a second launch shares out in work items of about 32 output segments (a highly
  * compressed stream: every tile; a long fill inside incompressible data: that tile) -- correct for every stream,
- * the faster one up to about 7 groups per word (the stream is read once) and as fast from about 32 on.  TWO LAUNCHES
- * (a scan of the stream + an expansion pass, as _scan_device + _expand_device): 15-25 % faster between 8 and 30 groups
- * per word, where the one pass finds out tile by tile that everything goes onto its list.  Without a pass over the
+ * the faster one up to about 7 groups per word (by 13-19 %: the stream is read once) and from about 200 on (3-6 %).
+ * TWO LAUNCHES (a scan of the stream + an expansion pass, as _scan_device + _expand_device): about 20 % faster between 8
+ * and 30 groups per word, where the one pass finds out tile by tile that everything goes onto its list, and within 1.5 %
+ * from there to 200.  Without a pass over the
  * stream the library cannot know which it holds, so the DEFAULT goes by what out_capacity_words allows it to be: at most
  * 7 words of output per word of stream, or more than 40: one pass; between: two launches.  A caller who knows the
  * stream passes WAH_ONE_PASS or WAH_TWO_LAUNCHES (wah_decompress_device_ex); decompress(), which has the stream in
- * host memory, samples it.  A stream that is only 4-byte aligned and WAH_NO_WAIT: always the two launches.
+ * host memory, samples it (one pass up to 7 groups per word and from 128 on).  A stream that is only 4-byte aligned and WAH_NO_WAIT: always the two launches.
  * wah_last_decode_route() says which one the calling thread's last call launched.
  * On ANY status other than WAH_OK the content of d_out is undefined: on WAH_ERR_CAPACITY the one-pass decoder has
  * written the part that fits (it learns the size while it writes; nothing is ever written behind out_capacity_words),

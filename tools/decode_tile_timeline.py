@@ -2,7 +2,9 @@
 """Time line of decode_tile_kernel (DIAGNOSTIC build: the stamps overwrite the head of the output buffer): per workgroup = per
 BATCH of tiles (two tiles of 8192 words; WAH_DT_BATCH=1: one), when it started, had its last tile staged and all of them counted,
 published its total, had the first tile's start flags, knew its base, finished (s_memrealtime, 100 MHz).
-usage: python tools/decode_tile_timeline.py [sparse|dense ...]"""
+A workload `uI` is the uniform bitmap with one bit in 2^I (u9, u10: every tile goes onto the list; the list's launch is left out --
+WAH_DIAG_NO_LIST -- so that the stamps survive, and the route is forced to the one pass).
+usage: python tools/decode_tile_timeline.py [sparse|dense|u9 ...]"""
 import importlib
 import os
 import sys
@@ -16,12 +18,18 @@ import torch  # noqa: E402
 wah = importlib.import_module("gpu-wah_amd")
 n = 268435200
 for kind in sys.argv[1:] or ["sparse"]:
-    d = {"sparse": lambda: wah.gen_uniform_device(n, 1337, 0.01), "dense": lambda: wah.gen_uniform_device(n, 1337, 0.5)}[kind]()
+    listed = kind.startswith("u")
+    if listed:
+        os.environ["WAH_DIAG_NO_LIST"] = "1"
+    else:
+        os.environ.pop("WAH_DIAG_NO_LIST", None)
+    d = (wah.gen_uniform_device(n, 1337, 2.0 ** -int(kind[1:])) if listed else
+         {"sparse": lambda: wah.gen_uniform_device(n, 1337, 0.01), "dense": lambda: wah.gen_uniform_device(n, 1337, 0.5)}[kind]())
     comp = wah.DeviceCompressor(n)
     comp.run(d)
     stream = comp.result().clone()
     del comp
-    dec = wah.DeviceDecompressor(stream.numel(), n + 1)
+    dec = wah.DeviceDecompressor(stream.numel(), n + 1, one_pass=True)
     dec.run(stream)
     dec.status()
     dec.run(stream)
@@ -48,6 +56,10 @@ for kind in sys.argv[1:] or ["sparse"]:
     print(f"   -> barrier 3                                    {q(bar3 - base)}")
     print(f"   -> all tiles expanded, end                      {q(end - bar3)}")
     two = seg2 > 0
+    if listed:
+        two = np.zeros_like(two)
+        loop0 = setup = seg1 = loop_end = bar4 = bar3
+        loop1 = np.zeros_like(loop1)
     print(f"   wave 0, the batch's last tile: barrier 3 -> its segment loop   {q(loop0 - bar3)}")
     print(f"     first segment: flags, words in front (setup)                 {q(setup - loop0)}")
     print(f"     first segment: 16 steps issued                               {q(seg1 - setup)}")
