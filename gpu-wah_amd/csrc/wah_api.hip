@@ -230,7 +230,8 @@ struct HostCall {
         if (!keep) cache.release_locked();
     }
     // slot: which buffer of the set; a kept buffer that is large enough is handed out again as it is
-    bool alloc(int slot, void **p, size_t bytes, const char *what, bool *fresh = nullptr) {
+    // (quiet: a failure is the caller's to handle -- no message, no error text)
+    bool alloc(int slot, void **p, size_t bytes, const char *what, bool *fresh = nullptr, bool quiet = false) {
         if (bytes == 0) bytes = 16;
         if (fresh) *fresh = false;
         if (cache.buf[slot] && cache.cap[slot] >= bytes) {
@@ -243,6 +244,10 @@ struct HostCall {
         cache.cap[slot] = 0;
         hipError_t e = hipMalloc(p, bytes);
         if (e != hipSuccess) {
+            if (quiet) {
+                (void)hipGetLastError();
+                return false;
+            }
             set_err(what, e);
             std::fprintf(stderr, "wah: could not allocate %s (%zu bytes): %s\n", what, bytes, hipGetErrorString(e));
             return false;
@@ -1305,7 +1310,10 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     // phase: one bit in 2^11 = 32 groups per word 0.248 ms in one pass against 0.223, 2^12 0.223 / 0.210, 2^14 0.209 / 0.203 --
     // through this boundary the one-pass kernel's longer workgroups show on a stream of a few megabytes); above: the same.
     // (BEFORE the copy: a device left idle for the millisecond this takes starts its next kernel slower)
+    // The same sample says how large the bitmap will be, to a percent or so (exactly, for a stream of up to 65 536 words): see
+    // phase 2.
     int route = 1;
+    uint64_t expect_words = 0; // decoded words the sample predicts (0: no prediction)
     if (c_words) {
         uint64_t sampled = 0, sample_groups = 0;
         const uint64_t stride = c_words > 65536 ? c_words / 65536 : 1;
@@ -1313,6 +1321,8 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
             sample_groups += (comp_host[i] & wah::kFillZero) ? (comp_host[i] & wah::kCountMask) : 1u;
         const uint64_t per_word = sample_groups / (sampled ? sampled : 1);
         route = (per_word <= 7 || per_word >= 128) ? 1 : 2;
+        const unsigned __int128 groups = (unsigned __int128)sample_groups * c_words / (sampled ? sampled : 1);
+        if (groups < ((unsigned __int128)1 << 40)) expect_words = ((uint64_t)groups * 31u + 31u) / 32u;
     }
     if (c_words && !hip_ok(hipMemcpy(d_comp, comp_host, c_words * sizeof(uint32_t), hipMemcpyHostToDevice), "copy input"))
         return nullptr;
@@ -1327,7 +1337,18 @@ uint32_t *wah_decompress(const uint32_t *comp_host, uint64_t c_words, uint64_t *
     // An output buffer kept from an earlier call (the reference's callers decompress in loops, source.cpp:70): expand
     // right behind the scan, into what is there -- the expand kernel compares the decoded size with the capacity on the
     // device and writes nothing if it does not fit.  One host round trip for the whole phase instead of two.
-    const size_t kept_words = hc.keep && hc.cache.buf[0] ? hc.cache.cap[0] / sizeof(uint32_t) : 0;
+    // Without one -- a process's first call, a bitmap larger than any before -- the reference's order (scan, read the size back,
+    // allocate, expand: decompress.cu:72-100) would read the stream twice and wait for the device twice: instead a buffer of
+    // the size the SAMPLE predicts, plus a sixteenth (+ 64 Ki words: a sample of 65 536 words is good to about a percent), and
+    // the same single pass.  A prediction that was too small costs what a kept buffer that is too small costs: the decoder
+    // reports WAH_ERR_CAPACITY and the call goes by the book below; a buffer the device cannot give: by the book, too.
+    size_t kept_words = hc.cache.buf[0] ? hc.cache.cap[0] / sizeof(uint32_t) : 0;
+    if (c_words && expect_words && kept_words < expect_words) {
+        const uint64_t want = expect_words + expect_words / 16u + 65536u;
+        void *grown = nullptr;
+        if (hc.alloc(0, &grown, want * sizeof(uint32_t), "space for the result", nullptr, true)) kept_words = want;
+        else kept_words = 0; // (alloc has dropped the smaller buffer)
+    }
     if (c_words && kept_words) {
         rc = decode_common(static_cast<uint32_t *>(d_comp), c_words, static_cast<uint32_t *>(hc.cache.buf[0]), kept_words, d_info, d_ws0,
                            ws0, nullptr, true, true, false, nullptr, false, route);

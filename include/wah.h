@@ -78,8 +78,11 @@ void wah_free(void *p);
  * decompress() does not know the decoded size before it has scanned the stream (nor does the reference,
  * decompress.cu:72-97).  With a kept buffer that is large enough -- the one a compress() or decompress() of this
  * process left behind: the reference's callers run them in turn on one size, source.cpp:70-103 -- it decodes into it in
- * ONE pass, one host round trip; without one (a process's first call, a larger bitmap than any before) it scans the
- * stream, reads the size back, allocates and expands: two passes over the stream, two round trips.
+ * ONE pass, one host round trip; without one (a process's first call, a larger bitmap than any before) it sizes one
+ * from a sample of the stream in host memory (the group counts of 65 536 words spread evenly over it, plus a
+ * sixteenth) and does the same.  Only when that prediction was too small (a foreign stream whose long fills the sample
+ * missed) does it go by the reference's order: scan the stream, read the size back, allocate, expand -- two passes
+ * over the stream, two round trips.
  *
  * Environment read by the library (nothing else is; the experiment switches of tools/ exist only in builds made with
  * -DWAH_EXPERIMENTS): WAH_HOST_CACHE=0 (above); WAH_FORCE_FALLBACK=1 (every launch by its no-wait route, below);

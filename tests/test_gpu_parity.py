@@ -519,6 +519,34 @@ def test_host_decompress_kept_output_buffer(wah, oracle):
         wah.decompress(np.full(1 << 18, 0xBFFFFFFF, np.uint32))
 
 
+def test_host_decompress_first_call_is_one_pass(wah, oracle):
+    """A process's first decompress() -- no output buffer kept -- sizes one from a sample of the stream (include/wah.h) and
+    decodes in the single pass it would take with a kept buffer (the reference's order, scan -> read the size back -> allocate
+    -> expand, decompress.cu:72-100, only when the prediction was too small).  The library says which decoder its last launch
+    was: the one-pass decoder after a first call on an incompressible stream; after a first call whose sample MISSES a giant
+    fill (a foreign stream: every sampled word is a literal) the expand-only launch of the by-the-book path -- and the same
+    words either way."""
+    lib = wah.lib()
+    n = 992 * 3000 + 17
+    data = oracle.gen_uniform(n, 5, 0.5)
+    comp = oracle.compress(data)
+    want = oracle.decompress(comp)
+    wah.host_cache_release()
+    assert np.array_equal(wah.decompress(comp), want)
+    assert lib.wah_last_decode_route() == 1, "first call: one pass into a buffer sized by the sample"
+    # 2 * 65536 + 2 words: the sample takes every second one; the giant fill sits on an odd index
+    foreign = np.full(2 * 65536 + 2, 0x2AAAAAAA, np.uint32)
+    foreign[1001] = 0x80000000 | 40_000_000  # a zero fill of 4e7 groups
+    want = oracle.decompress(foreign)
+    wah.host_cache_release()
+    got = wah.decompress(foreign)
+    assert np.array_equal(got, want)
+    assert lib.wah_last_decode_route() == 2, "prediction too small: scan, allocate, expand"
+    assert np.array_equal(wah.decompress(foreign), want)  # (now into the kept buffer)
+    assert lib.wah_last_decode_route() == 1
+    wah.host_cache_release()
+
+
 def test_compress_count_slots_and_streams(wah, oracle):
     """DeviceCompressor.run(count=slot, stream=s): launches of several compressors on several streams, every launch
     writing its C into its own slot (the columns workload of bench.py)."""
