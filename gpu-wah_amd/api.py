@@ -64,6 +64,7 @@ ABI_SYMBOLS = {
     "wah_gen_clustered_device": (_int, [_vp, _u64, _u64, _u64, _vp]),
     "wah_copy_device": (_int, [_vp, _vp, _u64, _vp]),
     "wah_last_decode_route": (_int, []),
+    "wah_last_bitop_route": (_int, []),
     "wah_last_error": (ctypes.c_char_p, []),
     "wah_version": (ctypes.c_char_p, []),
 }

@@ -323,6 +323,7 @@ bool test_timeout_hook() {
 }
 
 thread_local int g_last_route = wah::kRouteNone; // which decoder the calling thread's last decode call launched
+thread_local int g_last_bitop_route = 0;         // ... and which route its last indexed bit operation took (WAH_BITOP_ROUTE_*)
 
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
@@ -792,6 +793,7 @@ int wah_decompress_device_ex(const uint32_t *d_comp, uint64_t c_words, uint32_t 
 }
 
 int wah_last_decode_route(void) { return g_last_route; }
+int wah_last_bitop_route(void) { return g_last_bitop_route; }
 
 int wah_decompress_scan_device(const uint32_t *d_comp, uint64_t c_words, uint64_t *d_out_info, void *d_workspace,
                                size_t workspace_bytes, void *stream) {
@@ -1066,19 +1068,79 @@ int wah_decompress_segments_device(const uint32_t *d_comp, uint64_t c_words, con
 
 namespace {
 // scratch of wah_bitop_indexed_device: [control block of the combining pass][combined decoded bitmap][compress workspace]
+constexpr uint64_t kRunsMaxWordsPerSeg = 112; // (bitop_runs_route below)
+// (on the run-merge route the bitmap area holds the result's words per segment and per tile of segments instead)
 struct BitopIndexedLayout {
     size_t bitmap, ws_c, total;
     size_t ws_c_bytes;
     uint64_t decoded_capacity;
+    size_t runs_tiles, runs_temp; // run-merge route: the tile totals and the temporary, behind the segment counts at `bitmap`
 };
 BitopIndexedLayout bitop_indexed_layout(uint64_t n_words) {
     BitopIndexedLayout l;
     l.decoded_capacity = n_words + 1; // ceil(31 G / 32) is n_words or n_words + 1
     l.ws_c_bytes = wah_compress_workspace_bytes(n_words);
     l.bitmap = round256(wah::kCtlWords * sizeof(uint32_t));
-    l.ws_c = l.bitmap + round256(l.decoded_capacity * sizeof(uint32_t));
+    const uint64_t n_segments = ceil_div(wah_max_compressed_words(n_words), (uint64_t)wah::kSegGroups);
+    l.runs_tiles = l.bitmap + round256(n_segments * sizeof(uint32_t));
+    l.runs_temp = l.runs_tiles + round256((n_segments / 64 + 2) * sizeof(uint64_t));
+    const size_t runs_end = l.runs_temp + round256((kRunsMaxWordsPerSeg * n_segments + 16) * sizeof(uint32_t));
+    const size_t bitmap_end = l.bitmap + round256(l.decoded_capacity * sizeof(uint32_t));
+    l.ws_c = runs_end > bitmap_end ? runs_end : bitmap_end;
     l.total = l.ws_c + round256(l.ws_c_bytes);
     return l;
+}
+
+// The run-merge route (wah_bitop_runs.hip) for operands of few words per segment: all operands together at most
+// kRunsMaxWordsPerSeg words per segment on average -- the decode-based routes cost the same whatever the operands hold
+// (about 0.25 ms per operand + 0.2 ms on a 1 GiB bitmap), a merge costs by the word (tools/bitop_density_time.py: two operands
+// of 33 words per segment together 0.09 ms against 0.52, 63: 0.17, 122: 0.49-0.65 against 0.50-0.55; eight of 131 together:
+// 1.1-1.3 against 1.6, of 250: 7.4).  false: not taken (the caller goes on with its own route); rc: what the call returns when taken.
+bool bitop_runs_route(int op, uint64_t n_words, int n, const uint32_t *const *comp, const uint64_t *c_words, const uint64_t *const *offs,
+                      uint32_t *d_out, uint64_t out_capacity_words, uint64_t *d_out_words, uint64_t *d_out_offsets, char *sc,
+                      const BitopIndexedLayout &l, hipStream_t s, int *rc) {
+    const uint64_t groups = wah_max_compressed_words(n_words);
+    const uint64_t n_segments = ceil_div(groups, (uint64_t)wah::kSegGroups);
+    uint64_t total = 0;
+    for (int j = 0; j < n; ++j) total += c_words[j];
+    g_last_bitop_route = WAH_BITOP_ROUTE_GROUPS;
+    const char *force = wah::experiment_env("WAH_BITOP_ROUTE"); // (experiment builds: "runs" / "groups", tools/bitop_density_time.py)
+    const uint64_t temp_words = (l.ws_c - l.runs_temp) / sizeof(uint32_t);
+    if (n_words == 0 || total + 16 > temp_words || (force ? force[0] != 'r' : total > kRunsMaxWordsPerSeg * n_segments)) return false;
+    g_last_bitop_route = WAH_BITOP_ROUTE_RUNS;
+    if (!d_out_words || !d_out) {
+        set_err("null pointer");
+        *rc = WAH_ERR_ARG;
+        return true;
+    }
+    wah::BitopRunsArgs a = {};
+    for (int j = 0; j < n; ++j) {
+        a.comp[j] = comp[j];
+        a.c_words[j] = c_words[j];
+        a.offs[j] = offs[j];
+    }
+    a.n = n;
+    a.op = op;
+    a.groups = groups;
+    a.n_segments = n_segments;
+    a.seg_count = reinterpret_cast<uint32_t *>(sc + l.bitmap);
+    a.tile_total = reinterpret_cast<uint64_t *>(sc + l.runs_tiles);
+    a.temp = reinterpret_cast<uint32_t *>(sc + l.runs_temp);
+    a.out = d_out;
+    a.out_capacity = out_capacity_words;
+    a.out_words = d_out_words;
+    a.out_offsets = d_out_offsets;
+    a.ctrl = reinterpret_cast<uint32_t *>(sc);
+    // (both control blocks wah_bitop_indexed_status reads: this route's, and the compress workspace's, which it does not use)
+    hipError_t e = wah::launch_clear(sc + l.ws_c, wah::kCtlWords * sizeof(uint32_t), s);
+    if (e == hipSuccess) e = wah::launch_bitop_runs(a, s);
+    if (e != hipSuccess) {
+        set_err("run-merge launch", e);
+        *rc = WAH_ERR_HIP;
+        return true;
+    }
+    *rc = WAH_OK;
+    return true;
 }
 } // namespace
 
@@ -1113,6 +1175,13 @@ int wah_bitop_indexed_device(int op, uint64_t n_words, const uint32_t *d_a, uint
     if (e != hipSuccess) {
         set_err("clearing the scratch", e);
         return WAH_ERR_HIP;
+    }
+    {
+        const uint32_t *const comp[2] = {d_a, d_b};
+        const uint64_t words[2] = {a_words, b_words};
+        const uint64_t *const offs[2] = {d_a_offsets, d_b_offsets};
+        int rc = WAH_OK;
+        if (bitop_runs_route(op, n_words, 2, comp, words, offs, d_out, out_capacity_words, d_out_words, d_out_offsets, sc, l, s, &rc)) return rc;
     }
     wah::BitopOperands ops;
     ops.comp_a = d_a;
@@ -1162,6 +1231,12 @@ int wah_bitop_many_indexed_device(int op, uint64_t n_words, int n_operands, cons
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint64_t groups = wah_max_compressed_words(n_words);
     hipError_t e = wah::launch_clear(sc, wah::kCtlWords * sizeof(uint32_t), s);
+    if (e == hipSuccess) {
+        int rc = WAH_OK;
+        if (bitop_runs_route(op, n_words, n_operands, d_streams, stream_words, d_offsets, d_out, out_capacity_words, d_out_words,
+                             d_out_offsets, sc, l, s, &rc))
+            return rc;
+    }
     if (e == hipSuccess) {
         a.g.first_segment = 0;
         a.g.n_segments = (groups + wah::kSegGroups - 1) / wah::kSegGroups;

@@ -209,6 +209,26 @@ struct BitopManyArgs {
     int op; // WAH_OP_*
 };
 
+// ... on operands of few words per segment: their runs merged in the compressed domain, one lane per segment
+// (wah_bitop_runs.hip): count pass, scan of the tile totals, write pass
+struct BitopRunsArgs {
+    const uint32_t *comp[kMaxBitopOperands];
+    uint64_t c_words[kMaxBitopOperands];
+    const uint64_t *offs[kMaxBitopOperands];
+    int n;  // operands
+    int op; // WAH_OP_*
+    uint64_t groups, n_segments;
+    uint32_t *seg_count;  // scratch: n_segments
+    uint64_t *tile_total; // scratch: one entry per tile of segments: its words, then the words in front of it
+    uint32_t *temp;       // scratch: the segments' results before they are moved together: sum of c_words + 16 words
+    uint32_t *out;
+    uint64_t out_capacity;
+    uint64_t *out_words;
+    uint64_t *out_offsets; // optional, n_segments + 1 entries
+    uint32_t *ctrl;
+};
+hipError_t launch_bitop_runs(const BitopRunsArgs &a, hipStream_t s);
+
 // wah_bitop_device: what the operands' decodes left behind, checked on the device before the combining pass
 struct PairCheck {
     const uint64_t *info_a, *info_b; // [decoded words, groups] of the two operands

@@ -338,6 +338,18 @@ int wah_bitop_indexed_device(int op, uint64_t n_words, const uint32_t *d_a, uint
                              size_t scratch_bytes, void *stream);
 int wah_bitop_indexed_status(void *d_scratch, uint64_t n_words, void *stream);
 
+/* Two routes, the same words out of both (the library chooses by the operands' lengths; wah_last_bitop_route() says which
+ * the calling thread's last wah_bitop_indexed_device / wah_bitop_many_indexed_device call took):
+ * WAH_BITOP_ROUTE_RUNS -- all operands together hold at most 112 words per 1024-group segment on average (sparse or
+ * clustered bitmaps, what a bitmap index mostly holds): their run lists are MERGED in the compressed domain, one lane per
+ * segment, the way WAH operations are done on a CPU; nothing is decoded, nothing of bitmap size is written, the cost goes
+ * with the operands' words (count pass, scan of 1/256 of the segment counts, write pass: the operands are read twice).
+ * WAH_BITOP_ROUTE_GROUPS -- anything else: every segment decoded into its 1024 groups, combined in registers and
+ * compressed again (the description above); the cost goes with the bitmap's length. */
+#define WAH_BITOP_ROUTE_RUNS 1
+#define WAH_BITOP_ROUTE_GROUPS 2
+int wah_last_bitop_route(void);
+
 /* The same for up to 8 operands in ONE combining pass, left to right: A op B op C ... (WAH_OP_ANDNOT: A and not B
  * and not C ...) -- the conjunction of several predicates of a bitmap index in one go.  d_streams / stream_words /
  * d_offsets: HOST arrays of n_operands device pointers / lengths / index pointers.  Scratch and status as for

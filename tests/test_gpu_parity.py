@@ -738,6 +738,67 @@ def test_many_operand_bitops_through_the_segment_indexes(wah, oracle):
         wah.bitop_many_indexed_device("or", [ops[0], ops[1], (ops[2][0], bad)], n)
 
 
+def test_bitops_by_run_merge(wah, oracle):
+    """Operands of few words per segment (include/wah.h: WAH_BITOP_ROUTE_RUNS): the operands' runs merged in the compressed
+    domain, one lane per segment -- the same words and the same index as compress() of the combined bitmap, for every operation,
+    1..8 operands, ragged lengths (a last segment of few groups, a last group of few bits), a dense stretch inside sparse
+    operands (a tile whose words do not fit the LDS is read from global memory), all-zero and all-one bitmaps; corrupt operands
+    and too small an output are refused."""
+    import torch
+
+    lib = wah.lib()
+    fold = {"and": lambda xs: np.bitwise_and.reduce(xs), "or": lambda xs: np.bitwise_or.reduce(xs),
+            "xor": lambda xs: np.bitwise_xor.reduce(xs), "andnot": lambda xs: xs[0] & ~np.bitwise_or.reduce(xs[1:]) if len(xs) > 1 else xs[0]}
+    for n in (992 * 700 + 9, 992 * 256, 992 * 64 + 991, 33, 1):
+        maps = [oracle.gen_clustered(n, 50 + j, 6000 + 1500 * j) if j % 2 == 0 else oracle.gen_uniform(n, 50 + j, 2.0 ** -(13 + j % 3)) for j in range(8)]
+        maps[3] = np.zeros(n, np.uint32)
+        maps[5] = np.full(n, 0xFFFFFFFF, np.uint32)
+        if n > 992 * 300:
+            maps[0] = maps[0].copy()
+            maps[0][992 * 300: 992 * 308] = oracle.gen_uniform(992 * 8, 3, 0.5)  # 8 incompressible segments: a tile that is not staged
+        ops = [_indexed_stream(wah, _dev(m)) for m in maps]
+        for k in (1, 2, 3, 4, 8):
+            for name, fn in fold.items():
+                combined = fn(np.stack(maps[:k])).astype(np.uint32)
+                want = oracle.compress(combined)
+                got, offs = wah.bitop_many_indexed_device(name, ops[:k], n)
+                assert lib.wah_last_bitop_route() == 1, (n, k, "run merge expected")
+                assert got.numel() == want.size and np.array_equal(_host(got), want), (n, k, name)
+                _, ref_offs = _indexed_stream(wah, _dev(combined))
+                assert np.array_equal(offs.cpu().numpy(), ref_offs.cpu().numpy()), (n, k, name)
+        for name, fn in fold.items():
+            want = oracle.compress(fn(np.stack(maps[:2])).astype(np.uint32))
+            got, offs = wah.bitop_indexed_device(name, *ops[0], *ops[1], n)
+            assert lib.wah_last_bitop_route() == 1 and np.array_equal(_host(got), want), (n, name)
+        # results chain (their index is right): (A and B) or C
+        ab, oab = wah.bitop_indexed_device("and", *ops[0], *ops[1], n)
+        abc, _ = wah.bitop_indexed_device("or", ab.clone(), oab.clone(), *ops[2], n)
+        assert np.array_equal(_host(abc), oracle.compress(((maps[0] & maps[1]) | maps[2]).astype(np.uint32))), n
+    # a dense operand beside it: the other route, the same call
+    n = 992 * 64
+    a, b = oracle.gen_clustered(n, 1, 4000), oracle.gen_uniform(n, 2, 0.3)
+    (sa, oa), (sb, ob) = (_indexed_stream(wah, _dev(x)) for x in (a, b))
+    got, _ = wah.bitop_indexed_device("xor", sa, oa, sb, ob, n)
+    assert lib.wah_last_bitop_route() == 2 and np.array_equal(_host(got), oracle.compress(a ^ b))
+    # refused: an index that is not the stream's, a fill that runs past its segment, an empty fill, too small an output
+    (sc_, oc) = _indexed_stream(wah, _dev(oracle.gen_clustered(n, 3, 4000)))
+    bad = oa.clone()
+    bad[3] += 1
+    for args in ((sa, bad, sc_, oc), (sc_, oc, sa, bad)):
+        with pytest.raises(wah.WahError):
+            wah.bitop_indexed_device("and", *args, n)
+    zeros = np.zeros(n, np.uint32)
+    sz, oz = _indexed_stream(wah, _dev(zeros))                     # 64 words: one zero fill of 1024 groups per segment
+    for word in (0x80000000 | 1025, 0x80000000, 0x80000000 | 1023):
+        broken = sz.clone()
+        broken[5] = word - (1 << 32) if word >= (1 << 31) else word
+        with pytest.raises(wah.WahError):
+            wah.bitop_indexed_device("or", broken, oz, sc_, oc, n)
+    small = torch.empty(3, dtype=torch.int32, device="cuda")
+    with pytest.raises(wah.WahError):
+        wah.bitop_indexed_device("or", sa, oa, sc_, oc, n, out=small)
+
+
 def torch_pad(t, n):
     """t extended to n entries by repeating its last one (an index that claims more segments than the stream has)."""
     import torch

@@ -47,7 +47,7 @@ for kind in sys.argv[1:] or ["sparse"]:
     loop0, setup, seg1, seg2, loop_end, bar4, loop1, nseg = (t[:, i] for i in range(8, 16))
     t0 = start.min()
     us = lambda x: x / 100.0
-    q = lambda x: f"{us(np.median(x)):.2f} (p10 {us(np.percentile(x, 10)):.2f}, p90 {us(np.percentile(x, 90)):.2f})"
+    q = lambda x: f"{us(np.median(x)):.2f} (p10 {us(np.percentile(x, 10)):.2f}, p90 {us(np.percentile(x, 90)):.2f})" if len(x) else "--"
     print(f"--- {kind}: {n_tiles} workgroups of {batch} x 8192 words, span {us(end.max() - t0):.1f} us")
     print(f"   start -> all tiles counted, the last one staged {q(staged - start)}")
     print(f"   -> barrier 1 (publish)                          {q(pub - staged)}")
