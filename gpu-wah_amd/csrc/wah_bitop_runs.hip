@@ -93,11 +93,11 @@ __device__ __forceinline__ u32 runs_merge(const Load &word, const u32 (&begin)[K
 // Pass 1: kTileSegs segments per workgroup, one per thread: the segment's result to temp[sum of the operands' offsets of the
 // segment ..) (room for as many words as the operands have there: see runs_merge), its length to seg_count, the tile's to
 // tile_total.
-// kStage = false: no LDS image at all (operands of more words per segment than it would hold: twice the waves per CU instead).
-template <int K, int kTileSegs, bool kStage>
-__global__ __launch_bounds__(kTileSegs) void bitop_runs_kernel(const BitopRunsArgs a) {
-    constexpr u32 kLdsWords = kStage ? kRunsLdsWords : 1u;
-    __shared__ u32 s_words[kLdsWords];
+// lds_words: the size of the LDS image this launch was given (dynamic: operands of very few words per segment get by with a
+// small one, and more workgroups per CU); 0: none at all.
+template <int K, int kTileSegs>
+__global__ __launch_bounds__(kTileSegs) void bitop_runs_kernel(const BitopRunsArgs a, u32 lds_words) {
+    extern __shared__ u32 s_words[];
     __shared__ u32 s_wave[kTileSegs / 64];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const u64 seg0 = (u64)blockIdx.x * kTileSegs;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kTileSegs) void bitop_runs_kernel(const BitopRunsAr
         region_ok &= r_lo[j] <= r_hi[j] && r_hi[j] <= a.c_words[j];
         total += region_ok ? r_hi[j] - r_lo[j] : 0u;
     }
-    const bool staged = kStage && region_ok && total <= kLdsWords;
+    const bool staged = region_ok && total <= lds_words && lds_words != 0u;
     u32 base[K]; // where operand j's words start in s_words
     if (staged) {
         u32 at = 0;
@@ -269,10 +269,14 @@ void launch_runs_k(const BitopRunsArgs &a, u64 n_tiles, hipStream_t s) {
         for (int j = 0; j < K; ++j) t += a.c_words[j];
         return t;
     }();
-    if (total * kTileSegs <= (u64)kRunsLdsWords * a.n_segments)
-        hipLaunchKernelGGL((bitop_runs_kernel<K, kTileSegs, true>), dim3((unsigned)n_tiles), dim3(kTileSegs), 0, s, a);
-    else
-        hipLaunchKernelGGL((bitop_runs_kernel<K, kTileSegs, false>), dim3((unsigned)n_tiles), dim3(kTileSegs), 0, s, a);
+    // the image: one and a half times an average tile's words, in KiB steps, at most kRunsLdsWords; none when even that would
+    // not hold an average tile
+    u32 lds_words = 0;
+    if (total * kTileSegs <= (u64)kRunsLdsWords * a.n_segments) {
+        const u64 want = (total * kTileSegs * 3u / 2u / a.n_segments + 1024u) & ~(u64)255u;
+        lds_words = (u32)(want < kRunsLdsWords ? want : kRunsLdsWords);
+    }
+    hipLaunchKernelGGL((bitop_runs_kernel<K, kTileSegs>), dim3((unsigned)n_tiles), dim3(kTileSegs), lds_words * sizeof(u32), s, a, lds_words);
     hipLaunchKernelGGL(bitop_runs_scan_kernel, dim3(1), dim3(1024), 0, s, a, n_tiles);
     hipLaunchKernelGGL((bitop_runs_place_kernel<K, kTileSegs>), dim3((unsigned)n_tiles), dim3(kTileSegs), 0, s, a);
 }

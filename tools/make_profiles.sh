@@ -36,7 +36,8 @@ out = "$out"
 with open(f"{out}/next_rows.txt", "w") as o:
     o.write("rocprofv3 --kernel-trace --stats -- python3 tools/next_rows_time.py <workload>   (1 GiB bitmaps, N = 268435200 words; every call 1 + 5 times)\n")
     o.write("algorithmic bytes: unsegmented encoder 4N + 4C_u; checker / sums pass 4C; index builder 4C + 8 per segment; merge count 4C, scatter 4C + 4C_u;\n")
-    o.write("fused AND of two indexed streams 4C_A + 4C_B + 4C_out; four-operand combining pass 4(C_A + .. + C_D) + 4N (one decoded bitmap written)\n")
+    o.write("fused AND of two indexed streams 4C_A + 4C_B + 4C_out; four-operand combining pass 4(C_A + .. + C_D) + 4N (one decoded bitmap written);\n")
+    o.write("run merge (operands of few words per segment): merge pass 4(C_A + ..) + 4C_out, placement pass 8C_out\n")
     for wl in ("sparse", "clustered"):
         meta = None
         try:
@@ -51,9 +52,12 @@ with open(f"{out}/next_rows.txt", "w") as o:
         d = collections.defaultdict(list)
         for f in glob.glob(f"{out}/kt_next_{wl}/**/*kernel_trace.csv", recursive=True):
             for r in csv.DictReader(open(f)):
-                m = re.search(r"(\w+_kernel)", r["Kernel_Name"])
+                m = re.search(r"(\w+_kernel)(<\d+)?", r["Kernel_Name"])
                 if m:
-                    d[m.group(1)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+                    d[m.group(1)].append(us)
+                    if m.group(2):  # (template kernels by their first argument too: bitop_runs_kernel<2, <4 -- the operand count)
+                        d[m.group(1) + m.group(2)].append(us)
         o.write(f"== {wl}: C = {meta['c_words']} words (C/N {meta['c_words']/meta['n_words']:.4f}), unsegmented {meta['c_unsegmented']} words\n")
         for k, b in meta["algorithmic_bytes"].items():
             v = d.get(k)

@@ -92,15 +92,23 @@ for kind in sys.argv[1:] or ["sparse", "clustered"]:
     calls["wah_bitop_indexed_device(AND, 2 operands)"] = timed(lambda: wah.bitop_indexed_device("and", a, oa, b, ob, n, scratch=isc, out=out, out_offsets=ooffs, check=False))
     assert lib.wah_bitop_indexed_status(isc.data_ptr(), n, sp) == 0
     got, _ = wah.bitop_indexed_device("and", a, oa, b, ob, n, scratch=isc, out=out, out_offsets=ooffs)
-    rows["bitop_tile_kernel"] = 4.0 * ca + 4.0 * cb + 4.0 * int(got.numel())
+    if lib.wah_last_bitop_route() == 1:  # operands of few words per segment: their runs merged (wah_bitop_runs.hip), then moved together
+        rows["bitop_runs_kernel<2"] = 4.0 * ca + 4.0 * cb + 4.0 * int(got.numel())
+        rows["bitop_runs_place_kernel<2"] = 8.0 * int(got.numel())
+    else:
+        rows["bitop_tile_kernel"] = 4.0 * ca + 4.0 * cb + 4.0 * int(got.numel())
 
     # ---- ... of four: one combining pass (read the four streams, write one decoded bitmap) + the compress kernel over that bitmap
     ops = [(a, oa), (b, ob), indexed(gen(99)), indexed(gen(7))]
     calls["wah_bitop_many_indexed_device(AND, 4 operands)"] = timed(lambda: wah.bitop_many_indexed_device("and", ops, n, scratch=isc, out=out, out_offsets=ooffs, check=False))
     assert lib.wah_bitop_indexed_status(isc.data_ptr(), n, sp) == 0
     got4, _ = wah.bitop_many_indexed_device("and", ops, n, scratch=isc, out=out, out_offsets=ooffs)
-    rows["bitop_many_segments_kernel"] = 4.0 * sum(int(s.numel()) for s, _ in ops) + 4.0 * wah.decoded_words(groups)
-    rows["compress_pair_kernel"] = 4.0 * n + 4.0 * int(got4.numel())  # (its launch inside the four-operand call)
+    if lib.wah_last_bitop_route() == 1:
+        rows["bitop_runs_kernel<4"] = 4.0 * sum(int(s.numel()) for s, _ in ops) + 4.0 * int(got4.numel())
+        rows["bitop_runs_place_kernel<4"] = 8.0 * int(got4.numel())
+    else:
+        rows["bitop_many_segments_kernel"] = 4.0 * sum(int(s.numel()) for s, _ in ops) + 4.0 * wah.decoded_words(groups)
+        rows["compress_pair_kernel"] = 4.0 * n + 4.0 * int(got4.numel())  # (its launch inside the four-operand call)
 
     print("NEXT_ROWS " + json.dumps({"workload": kind, "n_words": n, "c_words": ca, "c_unsegmented": c_un, "algorithmic_bytes": rows,
                                      "call_ms": {k: round(v, 4) for k, v in calls.items()}}), flush=True)
