@@ -1020,6 +1020,82 @@ __device__ __forceinline__ void seg_store(const SegStore &st, int s, u32 grp) {
     __builtin_amdgcn_raw_buffer_store_b32((grp >> st.o) | hi_part, st.rsrc, st.soff + 248u * s, 0, 0);
 }
 
+// One word of a segment into the segment's IMAGE in LDS (992 words = its 31 744 bits, zeroed): the word's groups begin at bit
+// 31 p.  A literal is OR-ed in as one or two pieces; a fill of zeros is nothing at all; a fill of ones ORs the partial words
+// at its two ends and leaves [first_full, last_full) to the wave (all ones: the callers' loop below).  The 31 -> 32 repack of
+// mergeWords (kernels.cu:375) is the addressing: groups abut in the image as they do in the bitmap.
+__device__ __forceinline__ void image_put(lds_u32_ptr img, u32 w, u32 p, u32 n, bool active, u32 &first_full, u32 &last_full) {
+    first_full = last_full = 0u;
+    if (!active) return;
+    const u32 bit0 = 31u * p, q = bit0 >> 5, sh = bit0 & 31u;
+    if ((int)w >= 0) { // literal: 31 bits from bit0 on
+        __hip_atomic_fetch_or(img + q, w << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (sh >= 2u) __hip_atomic_fetch_or(img + q + 1, w >> (32u - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (w & 0x40000000u) { // ones: bits [bit0, bit1)
+        const u32 bit1 = 31u * (p + n), q1 = bit1 >> 5, e = bit1 & 31u;
+        if (q == q1) {
+            __hip_atomic_fetch_or(img + q, (~0u << sh) & ~(~0u << e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (sh != 0u) __hip_atomic_fetch_or(img + q, ~0u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (e != 0u) __hip_atomic_fetch_or(img + q1, ~(~0u << e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            first_full = sh != 0u ? q + 1u : q;
+            last_full = q1;
+        }
+    }
+}
+// ... the whole words inside the wave's fills of ones (first_full < last_full in some lanes): every such fill by all lanes
+__device__ __forceinline__ void image_fill_ones(lds_u32_ptr img, u32 first_full, u32 last_full, u32 lane) {
+    u64 m = __ballot(first_full < last_full);
+    while (m != 0ull) {
+        const u32 l = (u32)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const u32 f = (u32)__builtin_amdgcn_readlane((int)first_full, l), e = (u32)__builtin_amdgcn_readlane((int)last_full, l);
+        for (u32 q = f + lane; q < e; q += 64u) img[q] = 0xFFFFFFFFu;
+    }
+}
+
+// A WHOLE segment (1024 groups, 992 words inside the bitmap, the output 16-byte aligned) by SCATTER: the image is zeroed, every
+// word of the segment puts itself where it belongs (positions by a wave scan per batch of 128 words), the image goes out as
+// four 16-byte stores per lane.  Against the gather (seg_mark + sixteen steps of rank, LDS read, decode, repack, dword store)
+// the work goes with the segment's WORDS, not with its groups -- and a fill of zeros, most of a sparse bitmap's groups, costs
+// nothing.  false: the words do not make up the segment (nothing stored).
+__device__ __forceinline__ bool seg_expand_scatter(const SegRange &rg, const u32 (&x0)[kSegBatches], const u32 (&x1)[kSegBatches], u32 *image,
+                                                   u32 *out, u32 lane) {
+    lds_u32_ptr img = (lds_u32_ptr)image;
+    uint4 *const img4 = reinterpret_cast<uint4 *>(image);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) img4[64 * i + (int)lane] = make_uint4(0, 0, 0, 0);
+    u32 pos = 0;
+    bool bad = rg.bad != 0u;
+#pragma unroll
+    for (int b = 0; b < kSegBatches; ++b) {
+        const u32 wi = 128u * b;
+        if (wi < rg.cnt) { // wave-uniform
+            const u32 i0 = wi + 2u * lane;
+            const bool in0 = i0 < rg.cnt, in1 = i0 + 1u < rg.cnt;
+            const u32 n0 = in0 ? min(word_groups(x0[b]), 2u * kSegGroups) : 0u, n1 = in1 ? min(word_groups(x1[b]), 2u * kSegGroups) : 0u;
+            bad |= (in0 && n0 == 0u) || (in1 && n1 == 0u);
+            const u32 incl = (wi + 128u <= rg.cnt && __ballot((int)(x0[b] | x1[b]) < 0) == 0) ? 2u * lane + 2u : wave_scan_incl32(n0 + n1);
+            const u32 p1 = pos + incl - n1, p0 = p1 - n0;
+            // (nothing is put outside the image, whatever the words say; the total below then fails)
+            u32 f0, e0, f1, e1;
+            image_put(img, x0[b], p0, n0, in0 && p0 + n0 <= kSegGroups, f0, e0);
+            image_put(img, x1[b], p1, n1, in1 && p1 + n1 <= kSegGroups, f1, e1);
+            image_fill_ones(img, f0, e0, lane);
+            image_fill_ones(img, f1, e1, lane);
+            pos += (u32)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    if (__ballot(bad) != 0ull || pos != kSegGroups) return false;
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(out, kSegWords * 4u);
+    u32x4 q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = reinterpret_cast<const u32x4 *>(image)[64 * i + (int)lane];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(q[i], rsrc, lane * 16u, 1024 * i, 0); // (behind word 991: dropped)
+    return true;
+}
+
 // segment first_segment + k of the bitmap, its words in x0/x1 -> a.out + 992 k
 __device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const SegRange &rg, const u32 (&x0)[kSegBatches],
                                            const u32 (&x1)[kSegBatches], unsigned char *flag, u32 *words, u32 lane) {
@@ -1030,6 +1106,15 @@ __device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const S
         store_constant_segment(a.out, k * kSegWords, kSegWords, only, lane);
         return;
     }
+    // (up to 768 words: 1 GiB clustered -- 16 words per segment -- 0.47-0.50 -> 0.55 of the roofline, sparse -- 476 -- 0.70 as by
+    //  gather; incompressible segments stay with the gather, 0.73: by scatter 0.69.  The kernel's time is two dependent round
+    //  trips and the stores' drain more than its instructions: a sparse segment's zero fills cost the scatter nothing, and it
+    //  is no faster for it.)
+    if (rg.cnt <= 768u && rg.nvalid == kSegGroups && (a.first_segment + k + 1) * kSegWords <= a.out_words && ((uintptr_t)a.out & 15u) == 0u) {
+        if (!seg_expand_scatter(rg, x0, x1, words, a.out + k * kSegWords, lane) && lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
+        return;
+    }
+    // (the bitmap's last segment, or an output that is only 4-byte aligned: by gather, clipped word by word)
     if (!seg_mark(rg, x0, x1, flag, words, lane)) {
         if (lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
         return;
