@@ -16,6 +16,14 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 M31 = 0x7FFFFFFF
+_FORCED_NO_WAIT = os.environ.get("WAH_FORCE_FALLBACK") == "1"
+
+
+def _route_is(got, want):
+    """The decoder a call took (DeviceDecompressor.route or wah_last_decode_route()) against the one the test expects; with
+    WAH_FORCE_FALLBACK=1 in the environment every call takes the no-wait route instead (include/wah.h), and the suite is run
+    that way too."""
+    return got in ("no wait", 3) if _FORCED_NO_WAIT else got == want
 
 
 @pytest.fixture(scope="module")
@@ -187,7 +195,11 @@ def test_decode_plain_tiles_and_lone_fills(wah, oracle):
     dec.run(_dev(base))
     with pytest.raises(wah.WahError):
         dec.status()
-    assert np.array_equal(_host(out[:cap]), want[:cap]) and bool((out[cap:] == 0x5A5A5A5A).all())
+    assert bool((out[cap:] == 0x5A5A5A5A).all())
+    if dec.route == "one pass":  # (it learns the size while it writes: the part that fits is there; the other routes write nothing)
+        assert np.array_equal(_host(out[:cap]), want[:cap])
+    else:                        # (WAH_FORCE_FALLBACK=1: the no-wait route)
+        assert _FORCED_NO_WAIT and bool((out[:cap] == 0x5A5A5A5A).all())
 
 
 # ---------------------------------------------------------------- distributions
@@ -533,7 +545,7 @@ def test_host_decompress_first_call_is_one_pass(wah, oracle):
     want = oracle.decompress(comp)
     wah.host_cache_release()
     assert np.array_equal(wah.decompress(comp), want)
-    assert lib.wah_last_decode_route() == 1, "first call: one pass into a buffer sized by the sample"
+    assert _route_is(lib.wah_last_decode_route(), 1), "first call: one pass into a buffer sized by the sample"
     # 2 * 65536 + 2 words: the sample takes every second one; the giant fill sits on an odd index
     foreign = np.full(2 * 65536 + 2, 0x2AAAAAAA, np.uint32)
     foreign[1001] = 0x80000000 | 40_000_000  # a zero fill of 4e7 groups
@@ -541,9 +553,9 @@ def test_host_decompress_first_call_is_one_pass(wah, oracle):
     wah.host_cache_release()
     got = wah.decompress(foreign)
     assert np.array_equal(got, want)
-    assert lib.wah_last_decode_route() == 2, "prediction too small: scan, allocate, expand"
+    assert lib.wah_last_decode_route() == 2, "prediction too small: scan, allocate, expand (the expand-only launch)"
     assert np.array_equal(wah.decompress(foreign), want)  # (now into the kept buffer)
-    assert lib.wah_last_decode_route() == 1
+    assert _route_is(lib.wah_last_decode_route(), 1)
     wah.host_cache_release()
 
 
@@ -879,7 +891,7 @@ def test_decode_mostly_empty_bitmap_with_dense_islands(wah, oracle):
     for kw, route in (({}, "one pass"), ({"two_launches": True}, "two launches"), ({"no_wait": True}, "no wait")):
         dec = wah.DeviceDecompressor(len(st), n + 1, **kw)
         dec.run(_dev(st))
-        assert dec.route == route
+        assert _route_is(dec.route, route)
         assert np.array_equal(_host(dec.result())[:n], x), route
         dec.run(_dev(st))  # (the list's counters change hands from launch to launch)
         assert np.array_equal(_host(dec.result())[:n], x), route
@@ -907,11 +919,11 @@ def test_decoder_route_is_a_property_of_the_stream(wah, oracle):
     for kw, route in (({}, "two launches"), ({"one_pass": True}, "one pass"), ({"two_launches": True}, "two launches")):
         dec = wah.DeviceDecompressor(len(st), n + 1, **kw)
         dec.run(_dev(st))
-        assert dec.route == route, (kw, dec.route)
+        assert _route_is(dec.route, route), (kw, dec.route)
         assert np.array_equal(_host(dec.result()), want), kw
     dec = wah.DeviceDecompressor(len(st), 64 * n)  # ... and with a capacity that says nothing, the decoder that is right for anything
     dec.run(_dev(st))
-    assert dec.route == "one pass" and np.array_equal(_host(dec.result()), want)
+    assert _route_is(dec.route, "one pass") and np.array_equal(_host(dec.result()), want)
     with pytest.raises(wah.WahError):
         wah.DeviceDecompressor(len(st), n + 1, one_pass=True, two_launches=True).run(_dev(st))
     for name, x, cap in (("dense, 64 x the capacity", dense, 64 * n), ("clustered", clustered, n + 1), ("mixed", mixed, 3 * n)):
@@ -920,7 +932,7 @@ def test_decoder_route_is_a_property_of_the_stream(wah, oracle):
         for kw, route in (({}, "one pass"), ({"two_launches": True}, "two launches"), ({"no_wait": True}, "no wait")):
             dec = wah.DeviceDecompressor(len(st), cap, **kw)
             dec.run(_dev(st))
-            assert dec.route == route, (name, dec.route)
+            assert _route_is(dec.route, route), (name, dec.route)
             assert np.array_equal(_host(dec.result()), want), (name, route)
             dec.run(_dev(st))
             assert np.array_equal(_host(dec.result()), want), (name, route, "again")
@@ -929,7 +941,7 @@ def test_decoder_route_is_a_property_of_the_stream(wah, oracle):
         shifted.copy_(_dev(st))
         dec = wah.DeviceDecompressor(len(st), cap)
         dec.run(shifted)
-        assert dec.route == "two launches" and np.array_equal(_host(dec.result()), want), name
+        assert _route_is(dec.route, "two launches") and np.array_equal(_host(dec.result()), want), name
         # too small a capacity: reported by both, nothing written behind it; the two launches write nothing at all, the one-pass
         # decoder what fits of the tiles it expands itself (all of them in the incompressible stream; the tiles on its list are
         # expanded by the launch behind it, which knows the size and writes nothing)
@@ -945,7 +957,7 @@ def test_decoder_route_is_a_property_of_the_stream(wah, oracle):
             assert bool((got[short:] == 0x5A5A5A5A).all()), (name, kw)
             if kw:
                 assert bool((got == 0x5A5A5A5A).all()), (name, "two launches write nothing")
-            elif name.startswith("dense"):
+            elif name.startswith("dense") and dec.route == "one pass":  # (not with WAH_FORCE_FALLBACK=1: the no-wait route)
                 assert np.array_equal(got[:short], want[:short]), (name, "one pass writes the part that fits")
 
 
@@ -977,7 +989,7 @@ def test_decode_listed_tiles_stage_only_their_words(wah, oracle):
             dec = wah.DeviceDecompressor(len(stream), cap, one_pass=True)
             for _ in range(2):
                 dec.run(_dev(stream))
-                assert dec.route == "one pass"
+                assert _route_is(dec.route, "one pass")
                 assert np.array_equal(_host(dec.result()), want), (name, cap)
 
 
