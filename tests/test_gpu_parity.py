@@ -811,6 +811,50 @@ def test_bitops_by_run_merge(wah, oracle):
         wah.bitop_indexed_device("or", sa, oa, sc_, oc, n, out=small)
 
 
+def _run_structured_bitmap(rng, n_words, mean_run_groups):
+    """A bitmap of long runs with a literal at most of their ends: run lengths (in bits) around the group, step and segment sizes."""
+    n_bits = n_words * 32
+    bits = np.zeros(n_bits, np.uint8)
+    pos = 0
+    lengths = np.array([1, 30, 31, 32, 61, 62, 63, 31 * 64, 31 * 64 + 1, 31 * 1023, 31 * 1024, 31 * 1024 + 1, 31 * 2048 + 5])
+    while pos < n_bits:
+        if rng.random() < 0.5:
+            ln = int(rng.geometric(1.0 / (31 * mean_run_groups)))
+        else:
+            ln = int(lengths[rng.integers(0, len(lengths))])
+        kind = int(rng.integers(0, 8))
+        if kind >= 6:  # a few random bits
+            ln = min(ln, 70)
+            bits[pos: pos + ln] = rng.integers(0, 2, min(ln, n_bits - pos))
+        else:
+            bits[pos: pos + ln] = kind & 1
+        pos += ln
+    return np.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bitops_by_run_merge_fuzz(wah, oracle, seed):
+    """Random run structures through the run merge: 2 .. 5 operands, every operation, bitmaps of a few segments up to a few
+    tiles of 256 segments, with a ragged end -- against compress() of the combined bitmaps, words and index."""
+    rng = np.random.default_rng(4000 + seed)
+    lib = wah.lib()
+    fold = {"and": lambda xs: np.bitwise_and.reduce(xs), "or": lambda xs: np.bitwise_or.reduce(xs),
+            "xor": lambda xs: np.bitwise_xor.reduce(xs), "andnot": lambda xs: xs[0] & ~np.bitwise_or.reduce(xs[1:])}
+    n = int(rng.choice([992 * 3 + 1, 992 * 40, 992 * 257 + 500, 992 * 600 + 31]))
+    k = int(rng.integers(2, 6))
+    maps = [_run_structured_bitmap(rng, n, int(rng.choice([60, 200, 900]))) for _ in range(k)]
+    ops = [_indexed_stream(wah, _dev(m)) for m in maps]
+    for name, fn in fold.items():
+        combined = fn(np.stack(maps)).astype(np.uint32)
+        want = oracle.compress(combined)
+        got, offs = wah.bitop_many_indexed_device(name, ops, n)
+        route = lib.wah_last_bitop_route()
+        assert got.numel() == want.size and np.array_equal(_host(got), want), (seed, n, k, name, route)
+        _, ref_offs = _indexed_stream(wah, _dev(combined))
+        assert np.array_equal(offs.cpu().numpy(), ref_offs.cpu().numpy()), (seed, n, k, name, route)
+    assert route == 1, (seed, n, k, "these operands are meant for the run merge", sum(int(o[0].numel()) for o in ops), n // 992)
+
+
 def torch_pad(t, n):
     """t extended to n entries by repeating its last one (an index that claims more segments than the stream has)."""
     import torch
