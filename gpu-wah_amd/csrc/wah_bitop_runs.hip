@@ -31,10 +31,20 @@ namespace {
 // a 128-byte line per word (one bit in 2^11, two operands, 63 words per segment: 0.55 ms without the image).
 constexpr u32 kRunsLdsWords = WAH_RUNS_LDS_WORDS;
 
-// the combination of two group values (31 bits): op is wave-uniform
-__device__ __forceinline__ u32 runs_combine(u32 r, u32 v, u32 op) {
-    const u32 w = op == 3u ? v ^ kOnes31 : v; // WAH_OP_ANDNOT: A and not B and not C ...
-    return op == 1u ? (r | w) : op == 2u ? (r ^ w) : (r & w);
+// the combination of two group values (31 bits) by the minterms of `acc op operand` (include/wah.h: WAH_OP_AND 0, OR 1, XOR 2,
+// ANDNOT 3: A and not B and not C ...): three masks, wave-uniform, made once -- no branch on the operation inside a step
+struct RunsOp {
+    u32 ab, a_nb, na_b;
+};
+__device__ __forceinline__ RunsOp runs_op(u32 op) {
+    RunsOp m;
+    m.ab = op <= 1u ? ~0u : 0u;
+    m.a_nb = op == 0u ? 0u : ~0u;
+    m.na_b = op == 1u || op == 2u ? ~0u : 0u;
+    return m;
+}
+__device__ __forceinline__ u32 runs_combine(u32 r, u32 v, const RunsOp &m) {
+    return ((r & v & m.ab) | (r & ~v & m.a_nb) | (~r & v & m.na_b)) & kOnes31;
 }
 
 // One segment of K operands merged by one lane, WITHOUT branches inside a step (the lanes of a wave are at different places
@@ -43,12 +53,17 @@ __device__ __forceinline__ u32 runs_combine(u32 r, u32 v, u32 op) {
 // at least one operand, and every output word begins with a step of its own), + K for operands that are not what the index
 // says.  Returns their number.  bad: an operand's words do not make up exactly `nvalid` groups, or a fill of count 0.
 template <int K, typename Load>
-__device__ __forceinline__ u32 runs_merge(const Load &word, const u32 (&begin)[K], const u32 (&end)[K], u32 nvalid, u32 op, u32 *o, bool &bad) {
+__device__ __forceinline__ u32 runs_merge(const Load &word, const u32 (&begin)[K], const u32 (&end)[K], u32 nvalid, u32 op, const __amdgpu_buffer_rsrc_t o,
+                                          u32 o_at, bool &bad) {
     u32 idx[K], rem[K], val[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) idx[j] = begin[j], rem[j] = 0u, val[j] = 0u;
+    const RunsOp mop = runs_op(op);
     u32 left = nvalid, n_out = 0u;
-    u32 ptype = 0u, pcount = 0u; // the fill that is being built: 0 none, 1 zeros, 2 ones
+    // the word that is being built -- a fill (its count grows in place) or a literal -- goes out when the next one begins: one
+    // store per step at most.  ptype: 0 none yet / a literal, 1 a fill of zeros, 2 of ones
+    u32 ptype = 0u, pending = 0u;
+    bool have = false;
     while (left != 0u) {
         u32 step = left;
         // (all operands' words asked for before the first is looked at; read whether needed or not, from an index inside the
@@ -73,18 +88,24 @@ __device__ __forceinline__ u32 runs_merge(const Load &word, const u32 (&begin)[K
         }
         u32 r = val[0];
 #pragma unroll
-        for (int j = 1; j < K; ++j) r = runs_combine(r, val[j], op);
+        for (int j = 1; j < K; ++j) r = runs_combine(r, val[j], mop);
 #pragma unroll
         for (int j = 0; j < K; ++j) rem[j] -= step;
         left -= step;
         const u32 type = r == 0u ? 1u : r == kOnes31 ? 2u : 0u;
         const bool same = type != 0u && type == ptype;
-        if (!same && ptype != 0u) o[n_out++] = (ptype == 2u ? kFillOne : kFillZero) | pcount; // the fill before ends here
-        if (type == 0u) o[n_out++] = r;
-        pcount = same ? pcount + step : step;
+        if (!same && have) {
+            __builtin_amdgcn_raw_buffer_store_b32(pending, o, (o_at + n_out) * 4u, 0, 0);
+            ++n_out;
+        }
+        pending = same ? pending + step : type == 0u ? r : (type == 2u ? kFillOne : kFillZero) | step;
         ptype = type;
+        have = true;
     }
-    if (ptype != 0u) o[n_out++] = (ptype == 2u ? kFillOne : kFillZero) | pcount;
+    if (have) {
+        __builtin_amdgcn_raw_buffer_store_b32(pending, o, (o_at + n_out) * 4u, 0, 0);
+        ++n_out;
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) bad |= rem[j] != 0u || idx[j] != end[j]; // (a fill that reaches past the segment; words left over)
     return n_out;
@@ -118,6 +139,12 @@ __global__ __launch_bounds__(kTileSegs) void bitop_runs_kernel(const BitopRunsAr
         total += region_ok ? r_hi[j] - r_lo[j] : 0u;
     }
     const bool staged = region_ok && total <= lds_words && lds_words != 0u;
+    // the tile's part of the temporary: [sum of r_lo, sum of r_hi) + K words (runs_merge)
+    u64 tile_at = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) tile_at += region_ok ? r_lo[j] : 0u;
+    const u64 tile_words = region_ok ? total + (u64)K : 0u;
+    const __amdgpu_buffer_rsrc_t o_rsrc = make_rsrc(a.temp + tile_at, tile_words < 0x3FFFFFFFull ? (u32)tile_words * 4u : 0xFFFFFFFCu);
     u32 base[K]; // where operand j's words start in s_words
     if (staged) {
         u32 at = 0;
@@ -145,11 +172,13 @@ __global__ __launch_bounds__(kTileSegs) void bitop_runs_kernel(const BitopRunsAr
             lo[j] = a.offs[j][seg];
             hi[j] = a.offs[j][seg + 1];
             // (every word of a stream of compress() holds at least one group)
-            bad |= lo[j] > hi[j] || hi[j] > a.c_words[j] || hi[j] - lo[j] > nvalid || hi[j] == lo[j] || (staged && (lo[j] < r_lo[j] || hi[j] > r_hi[j]));
+            bad |= lo[j] > hi[j] || hi[j] > a.c_words[j] || hi[j] - lo[j] > nvalid || hi[j] == lo[j] || !region_ok || lo[j] < r_lo[j] || hi[j] > r_hi[j];
             at += lo[j];
         }
         if (!bad) {
-            u32 *const o = a.temp + at;
+            // (the tile's part of the temporary behind one descriptor: 32-bit offsets in the stores; what a corrupt operand would
+            //  put behind it is dropped)
+            const u32 o_at = (u32)(at - tile_at);
             u32 begin[K], end[K];
             if (staged) {
 #pragma unroll
@@ -157,7 +186,7 @@ __global__ __launch_bounds__(kTileSegs) void bitop_runs_kernel(const BitopRunsAr
                     begin[j] = base[j] + (u32)(lo[j] - r_lo[j]);
                     end[j] = begin[j] + (u32)(hi[j] - lo[j]);
                 }
-                n_out = runs_merge<K>([&](int, u32 i) { return s_words[i]; }, begin, end, nvalid, op, o, bad);
+                n_out = runs_merge<K>([&](int, u32 i) { return s_words[i]; }, begin, end, nvalid, op, o_rsrc, o_at, bad);
             } else {
                 const u32 *p[K];
 #pragma unroll
@@ -166,7 +195,7 @@ __global__ __launch_bounds__(kTileSegs) void bitop_runs_kernel(const BitopRunsAr
                     begin[j] = 0u;
                     end[j] = (u32)(hi[j] - lo[j]);
                 }
-                n_out = runs_merge<K>([&](int j, u32 i) { return p[j][i]; }, begin, end, nvalid, op, o, bad);
+                n_out = runs_merge<K>([&](int j, u32 i) { return p[j][i]; }, begin, end, nvalid, op, o_rsrc, o_at, bad);
             }
         }
         if (bad) {
