@@ -26,9 +26,10 @@ namespace {
 #ifndef WAH_RUNS_LDS_WORDS
 #define WAH_RUNS_LDS_WORDS 10240
 #endif
-// staged words per workgroup, all operands together (40 KB: three workgroups per CU) -- of 256, 128 or 64 segments, by what the
-// operands hold on average: 40, 80 or 160 words per segment.  Reading the words from global memory lane by lane instead costs
-// a 128-byte line per word (one bit in 2^11, two operands, 63 words per segment: 0.55 ms without the image).
+// staged words per workgroup at most, all operands together (40 KB: three workgroups per CU; a launch asks for one and a half
+// times its average tile, launch_runs_k) -- a workgroup of 256, 128 or 64 segments, by what the operands hold on average: up
+// to 36, 72 or more words per segment.  Reading the words from global memory lane by lane instead costs a 128-byte line per
+// word (one bit in 2^11, two operands, 63 words per segment: 0.55 ms without the image, 0.15 with).
 constexpr u32 kRunsLdsWords = WAH_RUNS_LDS_WORDS;
 
 // the combination of two group values (31 bits) by the minterms of `acc op operand` (include/wah.h: WAH_OP_AND 0, OR 1, XOR 2,
