@@ -510,7 +510,7 @@ static int compress_device_impl(const uint32_t *d_in, const uint32_t *d_in2, int
 #ifdef WAH_DIAG
     {
         static const uint32_t tune = [] { // diagnostic build only: 77 / 78 = per-tile time line (tools/tile_timeline.py)
-            const char *e = wah::experiment_env("WAH_TUNE");
+            const char *e = std::getenv("WAH_TUNE"); // (this block exists in the diagnostic build only)
             return e ? (uint32_t)std::strtoul(e, nullptr, 0) : 0u;
         }();
         a.tune = tune;

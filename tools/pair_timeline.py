@@ -32,7 +32,7 @@ tile_segs = 16 * int(os.environ.get("WAH_WAVE_PAIRS", "3"))
 for kind in sys.argv[1:] or ["sparse"]:
     d = {"sparse": lambda: wah.gen_uniform_device(n, 1337, 0.01), "dense": lambda: wah.gen_uniform_device(n, 1337, 0.5),
          "clustered": lambda: wah.gen_clustered_device(n, 1337)}[kind]()
-    comp = wah.DeviceCompressor(n, indexed=True)
+    comp = wah.DeviceCompressor(n)
     comp.run(d)
     comp.status()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -42,26 +42,30 @@ for kind in sys.argv[1:] or ["sparse"]:
     ev[1].record()
     comp.status()
     print(f"--- {kind}: the stamped launch between two events on its stream: {ev[0].elapsed_time(ev[1]) * 1e3:.1f} us")
-    n_tiles = (270600 + tile_segs - 1) // tile_segs
-    t = comp.seg_offsets[: n_tiles * 8].cpu().numpy().reshape(n_tiles, 8).astype(np.int64)
-    start, pub, loaded, done, p1, p2, bar2 = (t[:, i] for i in range(7))
+    n_tiles = int(os.environ.get("N_TILES", "0")) or (270600 + tile_segs - 1) // tile_segs
+    cap = comp.capacity
+    # 8 x u64 per tile at the END of the output buffer, the last tile's first (wah_compress_pair.inc)
+    t = comp.out[: cap].view(torch.int64)[(cap // 2) - 8 * n_tiles: cap // 2].cpu().numpy().reshape(n_tiles, 8)[::-1].astype(np.int64)
+    keep = (t[:, 0] > 0) & (t[:, 7] >= t[:, 0])
+    print(f"({int(keep.sum())} of {n_tiles} rows kept)")
+    t = t[keep]
+    start, pub, loaded, done, p1, p2, bar2, end = (t[:, i] for i in range(8))
     t0 = start.min()
     us = lambda x: x * 1e3 / khz
     q = lambda x: f"{us(x.mean()):.2f} (p10 {us(np.percentile(x, 10)):.2f}, p90 {us(np.percentile(x, 90)):.2f})"
-    print(f"--- {kind}: {n_tiles} tiles of {tile_segs} segments, span {us(bar2.max() - t0):.1f} us")
+    print(f"--- {kind}: {n_tiles} tiles, span {us(end.max() - t0):.1f} us")
     print(f"   start -> first pair in registers   {q(loaded - start)}")
     print(f"   -> wave 0's pass 1 done            {q(p1 - loaded)}")
     print(f"   -> barrier 1 passed (publish)      {q(pub - p1)}")
     print(f"   -> pass 2 + parking done           {q(p2 - pub)}")
     print(f"   -> offset known                    {q(done - p2)}")
     print(f"   -> barrier 2 passed                {q(bar2 - done)}")
-    print(f"   tile life (without emission)       {q(bar2 - start)}")
+    print(f"   -> every wave's stores issued      {q(end - bar2)}")
+    print(f"   tile life                          {q(end - start)}")
     s = us(start - t0)
-    e = us(bar2 - t0)
-    for x in np.arange(0, e.max() + 10, 10.0):
-        print(f"   {x:6.1f} us: in flight {int(np.sum((s <= x) & (x < e))):4d}  started {int(np.sum(s <= x)):5d}")
-    es = np.sort(e)
-    ss = np.sort(s)[512:]
-    k = min(len(es), len(ss))
-    print(f"   mean (start of the (512 + i)-th tile) - (i-th end): {float(np.mean(ss[:k] - es[:k])):.2f} us")
+    e = us(end - t0)
+    order = np.argsort(s)
+    for x in np.arange(0, e.max() + 5, 5.0):
+        live = (s <= x) & (x < e)
+        print(f"   {x:6.1f} us: in flight {int(np.sum(live)):4d}  started {int(np.sum(s <= x)):5d}  ended {int(np.sum(e <= x)):5d}")
     del comp, d
