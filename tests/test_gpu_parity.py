@@ -556,6 +556,12 @@ def test_host_decompress_first_call_is_one_pass(wah, oracle):
     assert lib.wah_last_decode_route() == 2, "prediction too small: scan, allocate, expand (the expand-only launch)"
     assert np.array_equal(wah.decompress(foreign), want)  # (now into the kept buffer)
     assert _route_is(lib.wah_last_decode_route(), 1)
+    # ... and a stream of 8 to 128 groups per word (here: one bit in 2^10, about 17) goes by the scan + expansion launches, which
+    # are the faster decoder for it -- decided from the same sample
+    mid = oracle.gen_uniform(992 * 3000, 6, 2.0 ** -10)
+    cm = oracle.compress(mid)
+    assert np.array_equal(wah.decompress(cm)[: mid.size], mid)
+    assert _route_is(lib.wah_last_decode_route(), 2)
     wah.host_cache_release()
 
 
@@ -1582,6 +1588,60 @@ def test_decode_segments_through_the_index(wah, oracle, n):
             count = int(rng.integers(0, segs - first + 1))
             part = _host(wah.decompress_segments_device(stream, offs, n, first, count))
             assert np.array_equal(part, want[first * 992: (first + count) * 992]), (kind, first, count)
+
+
+def test_decode_segments_scatter_shapes(wah, oracle):
+    """The index decode expands whole segments of up to 768 words by SCATTER into an image of the segment (a literal OR-ed in
+    as one or two pieces, a fill of ones as its two ends + whole words), larger ones and the bitmap's last segment by gather
+    (gpu-wah_amd/csrc/wah_decode.hip: seg_expand_scatter).  The shapes that decide: all ones (one fill word per segment), ones
+    with single zero bits (fills of ones of every length and alignment between literals), literals and one-group fills
+    alternating, a literal in a segment's last group, segments of exactly 768 and 769 words, run lengths around the group and
+    the 32-bit word -- and an output buffer that is only 4-byte aligned (gather for every segment)."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    n = 992 * 24
+    cases = {}
+    cases["all ones"] = np.full(n, 0xFFFFFFFF, np.uint32)
+    holes = np.full(n * 32, 1, np.uint8)
+    holes[rng.integers(0, n * 32, 900)] = 0
+    cases["ones with holes"] = holes
+    alt = np.zeros(n * 32, np.uint8)
+    for g in range(0, n * 32 // 31):
+        alt[31 * g: 31 * g + 31] = 1 if g % 2 == 0 else rng.integers(0, 2, 31)
+    cases["one-group fills of ones between literals"] = alt
+    last = np.zeros(n * 32, np.uint8)
+    last[31 * 1023 + 30::31 * 1024] = 1          # the last bit of every segment's last group
+    last[31 * 1024 * 3: 31 * 1024 * 4] = 1       # a segment that is one fill of ones
+    cases["a literal in the last group"] = last
+    for words in (768, 769):
+        # a segment of exactly `words` words: words - 1 literals, then one fill over the rest (segments 2 and 5)
+        b = np.zeros(n * 32, np.uint8)
+        for seg in (2, 5):
+            g0 = 1024 * seg
+            for g in range(words - 1):
+                b[31 * (g0 + g) + (g % 31)] = 1
+            b[31 * (g0 + words - 1): 31 * (g0 + 1024)] = seg == 5
+        cases[f"{words} words in a segment"] = b
+    runs = np.zeros(n * 32, np.uint8)
+    pos, v = 0, 0
+    while pos < n * 32:
+        ln = int(rng.choice([1, 2, 30, 31, 32, 33, 62, 63, 64, 65, 31 * 5, 31 * 64 + 3, 31 * 700]))
+        runs[pos: pos + ln] = v
+        pos, v = pos + ln, 1 - v
+    cases["runs around the group and the word"] = runs
+    for name, c in cases.items():
+        a = c if c.dtype == np.uint32 else np.packbits(c[: n * 32].reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(np.uint32).ravel()
+        stream, offs = _indexed_stream(wah, _dev(a))
+        assert np.array_equal(_host(stream), oracle.compress(a)), name
+        got = _host(wah.decompress_segments_device(stream, offs, n))
+        assert np.array_equal(got[:n], a), name
+        # the same into a buffer that begins 4 bytes behind a 16-byte boundary, and a range in the middle
+        shifted = torch.empty(n + 8, dtype=torch.int32, device="cuda")[1:]
+        got = _host(wah.decompress_segments_device(stream, offs, n, out=shifted))
+        assert np.array_equal(got[:n], a), (name, "4-byte aligned output")
+        part = _host(wah.decompress_segments_device(stream, offs, n, 3, 9))
+        assert np.array_equal(part, a[3 * 992: 12 * 992]), (name, "segments 3..11")
 
 
 def test_decode_segments_rejects_what_is_not_a_segmented_stream(wah, oracle):
