@@ -32,10 +32,19 @@ __device__ __forceinline__ SegRange seg_range(const SegmentsArgs &a, u64 seg, u6
 // the segment's words: 128 per batch, two per lane (reads past the range return 0)
 __device__ __forceinline__ void seg_load_words(const SegmentsArgs &a, const SegRange &r, u32 (&x0)[kSegBatches], u32 (&x1)[kSegBatches], u32 lane) {
     const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(a.comp + r.w0, r.cnt * 4u);
+    x0[0] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, 2u * lane * 4u, 0, 0);
+    x1[0] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, 2u * lane * 4u + 4u, 0, 0);
+    // (the batches behind the first under ONE wave-uniform test: a segment of a clustered bitmap has 16 words, fourteen of
+    //  the sixteen loads would come back as zeros)
+    if (r.cnt > 128u) {
 #pragma unroll
-    for (int b = 0; b < kSegBatches; ++b) {
-        x0[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u, 0, 0);
-        x1[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u + 4u, 0, 0);
+        for (int b = 1; b < kSegBatches; ++b) {
+            x0[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u, 0, 0);
+            x1[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u + 4u, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int b = 1; b < kSegBatches; ++b) x0[b] = x1[b] = 0u;
     }
 }
 
