@@ -1096,6 +1096,9 @@ __device__ __forceinline__ bool seg_expand_scatter(const SegRange &rg, const u32
     return true;
 }
 
+#ifndef WAH_SEG_SCATTER_MAX
+#define WAH_SEG_SCATTER_MAX 768u // words of a segment up to which it is expanded by scatter (seg_expand)
+#endif
 // segment first_segment + k of the bitmap, its words in x0/x1 -> a.out + 992 k
 __device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const SegRange &rg, const u32 (&x0)[kSegBatches],
                                            const u32 (&x1)[kSegBatches], unsigned char *flag, u32 *words, u32 lane) {
@@ -1110,7 +1113,7 @@ __device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const S
     //  gather; incompressible segments stay with the gather, 0.73: by scatter 0.69.  The kernel's time is two dependent round
     //  trips and the stores' drain more than its instructions: a sparse segment's zero fills cost the scatter nothing, and it
     //  is no faster for it.)
-    if (rg.cnt <= 768u && rg.nvalid == kSegGroups && (a.first_segment + k + 1) * kSegWords <= a.out_words && ((uintptr_t)a.out & 15u) == 0u) {
+    if (rg.cnt <= WAH_SEG_SCATTER_MAX && rg.nvalid == kSegGroups && (a.first_segment + k + 1) * kSegWords <= a.out_words && ((uintptr_t)a.out & 15u) == 0u) {
         if (!seg_expand_scatter(rg, x0, x1, words, a.out + k * kSegWords, lane) && lane == 0) atomicOr(a.ctrl + kCtlError, kErrStream);
         return;
     }

@@ -34,17 +34,23 @@ __device__ __forceinline__ void seg_load_words(const SegmentsArgs &a, const SegR
     const __amdgpu_buffer_rsrc_t in_rsrc = make_rsrc(a.comp + r.w0, r.cnt * 4u);
     x0[0] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, 2u * lane * 4u, 0, 0);
     x1[0] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, 2u * lane * 4u + 4u, 0, 0);
-    // (the batches behind the first under ONE wave-uniform test: a segment of a clustered bitmap has 16 words, fourteen of
-    //  the sixteen loads would come back as zeros)
+    // (the batches behind the first under wave-uniform tests -- 128, 512 words: a segment of a clustered bitmap has 16 words,
+    //  fourteen of the sixteen loads would come back as zeros; of the sparse bitmap 476: eight)
+#pragma unroll
+    for (int b = 1; b < kSegBatches; ++b) x0[b] = x1[b] = 0u;
     if (r.cnt > 128u) {
 #pragma unroll
-        for (int b = 1; b < kSegBatches; ++b) {
+        for (int b = 1; b < 4; ++b) {
             x0[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u, 0, 0);
             x1[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u + 4u, 0, 0);
         }
-    } else {
+        if (r.cnt > 512u) {
 #pragma unroll
-        for (int b = 1; b < kSegBatches; ++b) x0[b] = x1[b] = 0u;
+            for (int b = 4; b < kSegBatches; ++b) {
+                x0[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u, 0, 0);
+                x1[b] = __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, (128u * b + 2u * lane) * 4u + 4u, 0, 0);
+            }
+        }
     }
 }
 
