@@ -666,7 +666,7 @@ static int decode_common(const uint32_t *d_comp, uint64_t c_words, uint32_t *d_o
     // up to 7 groups per word (by 13-19 % against the two launches, which read the stream twice), as fast within 1.5 % from about
     // 32 groups per word on (every tile on the list: the list's launch is the expand kernel) and 3-6 % faster from about 200; in
     // between -- 8 to 30 groups per word -- the two launches win by about 20 % (tools/decode_density_time.py, 992 MiB, one bit in
-    // 2^9: 0.343 ms against 0.282, 2^10: 0.315 / 0.246 -- a stream of 60-130 MB is 2000-4000 workgroups of the tile kernel, whose
+    // 2^9: 0.338 ms against 0.282, 2^10: 0.280 / 0.243 -- a stream of 60-130 MB is 2000-4000 workgroups of the tile kernel, whose
     // tickets and list entries come out of one address each at 86 per microsecond: 98 us where the sums kernel takes 41).  The library cannot look at the stream without a pass over it, so the default goes by what the
     // CAPACITY allows the stream to be: at most 7 words of output per word of stream, or more than 40 -- one pass; between --
     // the two launches.  A caller who knows better says so (WAH_ONE_PASS / WAH_TWO_LAUNCHES); decompress(), which has the stream

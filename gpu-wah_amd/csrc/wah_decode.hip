@@ -614,6 +614,40 @@ __device__ __forceinline__ void store_constant_segment(u32 *out, u64 seg_w0, u32
     for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(q, rsrc, lane * 16u, 1024 * i, 0);
 }
 
+// One word of a segment into the segment's IMAGE in LDS (992 words = its 31 744 bits, zeroed): the word's groups begin at bit
+// 31 p.  A literal is OR-ed in as one or two pieces; a fill of zeros is nothing at all; a fill of ones ORs the partial words
+// at its two ends and leaves [first_full, last_full) to the wave (all ones: the callers' loop below).  The 31 -> 32 repack of
+// mergeWords (kernels.cu:375) is the addressing: groups abut in the image as they do in the bitmap.
+__device__ __forceinline__ void image_put(lds_u32_ptr img, u32 w, u32 p, u32 n, bool active, u32 &first_full, u32 &last_full) {
+    first_full = last_full = 0u;
+    if (!active) return;
+    const u32 bit0 = 31u * p, q = bit0 >> 5, sh = bit0 & 31u;
+    if ((int)w >= 0) { // literal: 31 bits from bit0 on
+        __hip_atomic_fetch_or(img + q, w << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (sh >= 2u) __hip_atomic_fetch_or(img + q + 1, w >> (32u - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (w & 0x40000000u) { // ones: bits [bit0, bit1)
+        const u32 bit1 = 31u * (p + n), q1 = bit1 >> 5, e = bit1 & 31u;
+        if (q == q1) {
+            __hip_atomic_fetch_or(img + q, (~0u << sh) & ~(~0u << e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            if (sh != 0u) __hip_atomic_fetch_or(img + q, ~0u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (e != 0u) __hip_atomic_fetch_or(img + q1, ~(~0u << e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            first_full = sh != 0u ? q + 1u : q;
+            last_full = q1;
+        }
+    }
+}
+// ... the whole words inside the wave's fills of ones (first_full < last_full in some lanes): every such fill by all lanes
+__device__ __forceinline__ void image_fill_ones(lds_u32_ptr img, u32 first_full, u32 last_full, u32 lane) {
+    u64 m = __ballot(first_full < last_full);
+    while (m != 0ull) {
+        const u32 l = (u32)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const u32 f = (u32)__builtin_amdgcn_readlane((int)first_full, l), e = (u32)__builtin_amdgcn_readlane((int)last_full, l);
+        for (u32 q = f + lane; q < e; q += 64u) img[q] = 0xFFFFFFFFu;
+    }
+}
+
 // ---- one output segment, fast version: the tile expands to fewer than 2^31 groups, so every position relative to the
 // segment start fits a signed 32-bit integer; bookkeeping stays in vector registers (see compress_kernel) ----------
 
@@ -621,9 +655,15 @@ __device__ __forceinline__ void store_constant_segment(u32 *out, u64 seg_w0, u32
 // segment start (<= 0 at first).  Flags the group at which every contributing word starts (clipped at the segment
 // start).  kFirst: returns the tile-local index of the first contributing word.
 // kFirst also: `whole` = the word that covers the WHOLE segment [0, nvalid), if one does (a fill: nonzero), else 0.
+// (what a lane's two words of the first batch are and which of the segment's groups they cover, clipped: for the scatter)
+struct MarkBatch {
+    u32 w0, w1;
+    int s0, e0, s1, e1;
+};
 template <bool kLocal, bool kFirst>
 __device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, u32 *s_words, unsigned char *flag, u64 tile_w0,
-                                          u32 left_in_stream, u32 nvalid, u32 lane, int &rel, u32 &wi, u32 *whole = nullptr) {
+                                          u32 left_in_stream, u32 nvalid, u32 lane, int &rel, u32 &wi, u32 *whole = nullptr,
+                                          MarkBatch *mb = nullptr) {
     const u32 i0 = wi + 2u * lane;
     u32 w0, w1;
     if (kLocal) {
@@ -644,6 +684,7 @@ __device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, u32 *s_words, uns
     const int s0 = lo0 > 0 ? lo0 : 0, e0 = lo1 < (int)nvalid ? lo1 : (int)nvalid;
     const int s1 = lo1 > 0 ? lo1 : 0, e1 = hi1 < (int)nvalid ? hi1 : (int)nvalid;
     const bool c0 = e0 > s0, c1 = e1 > s1;
+    if (kFirst && mb) *mb = MarkBatch{w0, w1, s0, e0, s1, e1};
     // distinct groups: plain byte stores, no atomics.  slot(p) + base = base + 16 p - 1023 (p / 64): three instructions
     const u32 fbase = (u32)(uintptr_t)(lds_u8_ptr)flag;
     const u32 dump = fbase + kSegGroups + lane;
@@ -667,6 +708,15 @@ __device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, u32 *s_words, uns
     return first;
 }
 
+#ifndef WAH_EXPAND_SCATTER
+#define WAH_EXPAND_SCATTER 0 // 1: decode_expand_kernel too
+#endif
+// kScatter (the list's launch, whose flag areas are 2 KB): a whole segment all of whose words lie in the first marking batch --
+// a highly compressed stream's: a clustered bitmap has 16 words per segment -- is expanded by SCATTER, half a segment at a time
+// (512 groups = 496 words: the image of a half fits the flag area): the half's image zeroed, every word of the batch puts the
+// part of itself that lies in the half where it belongs (image_put: a fill of zeros is nothing), two 16-byte stores per lane.
+// The work goes with the segment's words instead of sixteen steps of rank, gather, decode and repack whatever it holds.
+template <bool kScatter>
 __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, u32 *s_words, const u32 *s_coarse32,
                                                     unsigned char *flag, u64 tile_w0, u32 target, u32 nvalid,
                                                     u64 out_words, u64 seg, u32 lane) {
@@ -683,11 +733,33 @@ __device__ __forceinline__ void expand_segment_tame(const ExpandArgs &a, u32 *s_
     constexpr u32 kLastLocal = (u32)kScanTileWords - 128u; // batches starting up to here come out of the LDS tile
     // the word that covers the segment's first group is in the first batch (that is how the bucket was chosen)
     u32 whole = 0;
-    const u32 first_word = wi <= kLastLocal ? mark_pairs<true, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi, &whole)
-                                            : mark_pairs<false, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi, &whole);
+    MarkBatch mb;
+    const u32 first_word = wi <= kLastLocal ? mark_pairs<true, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi, &whole, &mb)
+                                            : mark_pairs<false, true>(a, s_words, flag, tile_w0, left_in_stream, nvalid, lane, rel, wi, &whole, &mb);
     if (whole != 0u && nvalid == kSegGroups && (seg + 1) * kSegWords <= out_words) { // (wave-uniform) the inside of a long fill
         const u64 seg_w0 = seg * kSegWords;
         store_constant_segment(a.out, seg_w0, kSegWords, whole, lane);
+        return;
+    }
+    if (kScatter && rel >= (int)nvalid && nvalid == kSegGroups && (seg + 1) * kSegWords <= out_words && ((uintptr_t)a.out & 15u) == 0u) {
+        lds_u32_ptr img = (lds_u32_ptr)reinterpret_cast<u32 *>(flag);
+        uint4 *const img4 = reinterpret_cast<uint4 *>(flag);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            img4[lane] = make_uint4(0, 0, 0, 0);
+            img4[64 + (int)lane] = make_uint4(0, 0, 0, 0);
+            const int g0 = 512 * h, g1 = g0 + 512;
+            const int s0 = mb.s0 > g0 ? mb.s0 : g0, e0 = mb.e0 < g1 ? mb.e0 : g1, s1 = mb.s1 > g0 ? mb.s1 : g0, e1 = mb.e1 < g1 ? mb.e1 : g1;
+            u32 f0, l0, f1, l1;
+            image_put(img, mb.w0, (u32)(s0 - g0), (u32)(e0 - s0), e0 > s0, f0, l0);
+            image_put(img, mb.w1, (u32)(s1 - g0), (u32)(e1 - s1), e1 > s1, f1, l1);
+            image_fill_ones(img, f0, l0, lane);
+            image_fill_ones(img, f1, l1, lane);
+            const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.out + seg * kSegWords + 496u * (u32)h, 1984u);
+            const u32x4 q0 = reinterpret_cast<const u32x4 *>(flag)[lane], q1 = reinterpret_cast<const u32x4 *>(flag)[64 + (int)lane];
+            __builtin_amdgcn_raw_buffer_store_b128(q0, rsrc, lane * 16u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(q1, rsrc, lane * 16u, 1024, 0); // (behind word 495 of the half: dropped)
+        }
         return;
     }
     while (rel < (int)nvalid && wi <= kLastLocal)
@@ -716,7 +788,8 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     __shared__ u64 s_coarse[kCoarse + 1]; // groups in front of word 64 c, relative to the tile start
     __shared__ u32 s_coarse32[kCoarse + 1]; // the same in 32 bits (valid when the tile total is below 2^31)
     __shared__ u64 s_wave_sum[kExpandWaves];
-    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][kFlagBytes]; // 1: a word starts at this group
+    // (the list's launch: 2 KB per wave -- the image of half a segment for expand_segment_tame's scatter)
+    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][(WAH_EXPAND_SCATTER || kContiguous) ? 2048u : kFlagBytes]; // 1: a word starts at this group
     // (the thread's number through an opaque move: inside the list launch's loop over work items everything derived from it --
     //  lane constants, LDS addresses -- would otherwise be made once in front of the loop and kept in registers across it: 123
     //  registers against the 70 of the routine on its own)
@@ -865,7 +938,7 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     for (u64 seg = seg_first; seg < seg_last; seg += kContiguous ? (u64)kExpandWaves : (u64)kExpandWaves * parts) {
         if (tame) {
             const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
-            expand_segment_tame(a, s_words, s_coarse32, flag, tile_w0, (u32)(seg * kSegGroups - base), nvalid, out_words, seg, lane);
+            expand_segment_tame<WAH_EXPAND_SCATTER || kContiguous>(a, s_words, s_coarse32, flag, tile_w0, (u32)(seg * kSegGroups - base), nvalid, out_words, seg, lane);
         } else {
             expand_segment_general(a, s_words, s_coarse, flag, tile_w0, base, groups, out_words, seg, lane);
         }
@@ -977,7 +1050,7 @@ __global__ __launch_bounds__(kExpandThreads) void decode_expand_kernel(const Exp
 }
 
 #ifndef WAH_LIST_MINW
-#define WAH_LIST_MINW 6 // (80 registers, nothing spilled -- with the thread's number made opaque inside the tile routine; without: 123)
+#define WAH_LIST_MINW 5 // (the flag areas of 2 KB per wave -- the scatter's half-segment image -- leave room for five workgroups per CU: up to 96 registers)
 #endif
 // the expand tiles decode_tile_kernel left to this route (giant fills, fill words of count 0: foreign streams), out of its
 // list; normally the list is empty and the launch ends at once.
@@ -1018,40 +1091,6 @@ __device__ __forceinline__ SegStore seg_store_setup(u32 *out, u64 out_words, u64
 __device__ __forceinline__ void seg_store(const SegStore &st, int s, u32 grp) {
     const u32 hi_part = (u32)__builtin_amdgcn_mov_dpp((int)(grp << st.up), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
     __builtin_amdgcn_raw_buffer_store_b32((grp >> st.o) | hi_part, st.rsrc, st.soff + 248u * s, 0, 0);
-}
-
-// One word of a segment into the segment's IMAGE in LDS (992 words = its 31 744 bits, zeroed): the word's groups begin at bit
-// 31 p.  A literal is OR-ed in as one or two pieces; a fill of zeros is nothing at all; a fill of ones ORs the partial words
-// at its two ends and leaves [first_full, last_full) to the wave (all ones: the callers' loop below).  The 31 -> 32 repack of
-// mergeWords (kernels.cu:375) is the addressing: groups abut in the image as they do in the bitmap.
-__device__ __forceinline__ void image_put(lds_u32_ptr img, u32 w, u32 p, u32 n, bool active, u32 &first_full, u32 &last_full) {
-    first_full = last_full = 0u;
-    if (!active) return;
-    const u32 bit0 = 31u * p, q = bit0 >> 5, sh = bit0 & 31u;
-    if ((int)w >= 0) { // literal: 31 bits from bit0 on
-        __hip_atomic_fetch_or(img + q, w << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (sh >= 2u) __hip_atomic_fetch_or(img + q + 1, w >> (32u - sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    } else if (w & 0x40000000u) { // ones: bits [bit0, bit1)
-        const u32 bit1 = 31u * (p + n), q1 = bit1 >> 5, e = bit1 & 31u;
-        if (q == q1) {
-            __hip_atomic_fetch_or(img + q, (~0u << sh) & ~(~0u << e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            if (sh != 0u) __hip_atomic_fetch_or(img + q, ~0u << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (e != 0u) __hip_atomic_fetch_or(img + q1, ~(~0u << e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            first_full = sh != 0u ? q + 1u : q;
-            last_full = q1;
-        }
-    }
-}
-// ... the whole words inside the wave's fills of ones (first_full < last_full in some lanes): every such fill by all lanes
-__device__ __forceinline__ void image_fill_ones(lds_u32_ptr img, u32 first_full, u32 last_full, u32 lane) {
-    u64 m = __ballot(first_full < last_full);
-    while (m != 0ull) {
-        const u32 l = (u32)__builtin_ctzll(m);
-        m &= m - 1ull;
-        const u32 f = (u32)__builtin_amdgcn_readlane((int)first_full, l), e = (u32)__builtin_amdgcn_readlane((int)last_full, l);
-        for (u32 q = f + lane; q < e; q += 64u) img[q] = 0xFFFFFFFFu;
-    }
 }
 
 // A WHOLE segment (1024 groups, 992 words inside the bitmap, the output 16-byte aligned) by SCATTER: the image is zeroed, every
@@ -1353,7 +1392,11 @@ hipError_t launch_decode_tiles(const ScanArgs &sa, const ExpandArgs &xa, u64 *de
     ExpandArgs x = xa;
     x.parts = 1;
     x.defer_list = nullptr; // (the list is this launch's own argument)
-    hipLaunchKernelGGL(decode_expand_list_kernel, dim3(defer_list_grid(xa.out_capacity, xa.c_words)), dim3(kExpandThreads), 0, s, x, (const u64 *)t.defer_list, (const u32 *)t.defer_count, t.defer_capacity, 0u);
+    static const unsigned list_dyn_lds = [] { // experiments only: dynamic LDS as an occupancy limiter (WAH_LIST_DYNLDS = bytes)
+        const char *e = experiment_env("WAH_LIST_DYNLDS");
+        return e ? (unsigned)std::strtoul(e, nullptr, 0) : 0u;
+    }();
+    hipLaunchKernelGGL(decode_expand_list_kernel, dim3(defer_list_grid(xa.out_capacity, xa.c_words)), dim3(kExpandThreads), list_dyn_lds, s, x, (const u64 *)t.defer_list, (const u32 *)t.defer_count, t.defer_capacity, 0u);
     return hipGetLastError();
 }
 
