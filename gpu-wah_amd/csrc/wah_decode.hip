@@ -711,6 +711,9 @@ __device__ __forceinline__ u32 mark_pairs(const ExpandArgs &a, u32 *s_words, uns
 #ifndef WAH_EXPAND_SCATTER
 #define WAH_EXPAND_SCATTER 0 // 1: decode_expand_kernel too
 #endif
+#ifndef WAH_LIST_SCATTER
+#define WAH_LIST_SCATTER 1 // the list's launch
+#endif
 // kScatter (the list's launch, whose flag areas are 2 KB): a whole segment all of whose words lie in the first marking batch --
 // a highly compressed stream's: a clustered bitmap has 16 words per segment -- is expanded by SCATTER, half a segment at a time
 // (512 groups = 496 words: the image of a half fits the flag area): the half's image zeroed, every word of the batch puts the
@@ -789,7 +792,7 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     __shared__ u32 s_coarse32[kCoarse + 1]; // the same in 32 bits (valid when the tile total is below 2^31)
     __shared__ u64 s_wave_sum[kExpandWaves];
     // (the list's launch: 2 KB per wave -- the image of half a segment for expand_segment_tame's scatter)
-    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][(WAH_EXPAND_SCATTER || kContiguous) ? 2048u : kFlagBytes]; // 1: a word starts at this group
+    __shared__ __attribute__((aligned(16))) unsigned char s_flag[kExpandWaves][(WAH_EXPAND_SCATTER || (WAH_LIST_SCATTER && kContiguous)) ? 2048u : kFlagBytes]; // 1: a word starts at this group
     // (the thread's number through an opaque move: inside the list launch's loop over work items everything derived from it --
     //  lane constants, LDS addresses -- would otherwise be made once in front of the loop and kept in registers across it: 123
     //  registers against the 70 of the routine on its own)
@@ -938,7 +941,7 @@ __device__ __forceinline__ void expand_tile(const ExpandArgs &a, u32 tile, u32 p
     for (u64 seg = seg_first; seg < seg_last; seg += kContiguous ? (u64)kExpandWaves : (u64)kExpandWaves * parts) {
         if (tame) {
             const u32 nvalid = (groups - seg * kSegGroups < kSegGroups) ? (u32)(groups - seg * kSegGroups) : kSegGroups;
-            expand_segment_tame<WAH_EXPAND_SCATTER || kContiguous>(a, s_words, s_coarse32, flag, tile_w0, (u32)(seg * kSegGroups - base), nvalid, out_words, seg, lane);
+            expand_segment_tame<WAH_EXPAND_SCATTER || (WAH_LIST_SCATTER && kContiguous)>(a, s_words, s_coarse32, flag, tile_w0, (u32)(seg * kSegGroups - base), nvalid, out_words, seg, lane);
         } else {
             expand_segment_general(a, s_words, s_coarse, flag, tile_w0, base, groups, out_words, seg, lane);
         }
@@ -1148,8 +1151,9 @@ __device__ __forceinline__ void seg_expand(const SegmentsArgs &a, u64 k, const S
         store_constant_segment(a.out, k * kSegWords, kSegWords, only, lane);
         return;
     }
-    // (up to 768 words: 1 GiB clustered -- 16 words per segment -- 0.47-0.50 -> 0.55 of the roofline, sparse -- 476 -- 0.70 as by
-    //  gather; incompressible segments stay with the gather, 0.73: by scatter 0.69.  The kernel's time is two dependent round
+    // (up to 768 words: 1 GiB clustered -- 16 words per segment -- 0.47-0.50 -> 0.55 of the roofline, 0.67-0.70 with seg_load_words
+    //  asking only for the words there are; sparse -- 476 -- 0.70 as by gather; incompressible segments stay with the gather,
+    //  0.73: by scatter 0.69.  The kernel's time is two dependent round
     //  trips and the stores' drain more than its instructions: a sparse segment's zero fills cost the scatter nothing, and it
     //  is no faster for it.)
     if (rg.cnt <= WAH_SEG_SCATTER_MAX && rg.nvalid == kSegGroups && (a.first_segment + k + 1) * kSegWords <= a.out_words && ((uintptr_t)a.out & 15u) == 0u) {
