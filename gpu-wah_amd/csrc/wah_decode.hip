@@ -1185,7 +1185,11 @@ __global__ __launch_bounds__(kSegDecodeWaves * 64) void decode_segments_kernel(c
     const u64 k = (u64)blockIdx.x * kSegDecodeWaves + wave;
     if (k >= a.n_segments) return;
     const u64 seg = a.first_segment + k;
-    const SegRange rg = seg_range(a, seg, uniform64(a.seg_offsets[seg]), uniform64(a.seg_offsets[seg + 1]));
+    // (the index is read-only for this launch and the segment's number the same in all lanes: through the scalar cache -- two of
+    //  a clustered segment's eight memory instructions are these)
+    typedef const __attribute__((address_space(4))) u64 *const_u64_ptr;
+    const const_u64_ptr offs = (const_u64_ptr)(uintptr_t)(a.seg_offsets + seg);
+    const SegRange rg = seg_range(a, seg, offs[0], offs[1]);
     u32 x0[kSegBatches], x1[kSegBatches];
     seg_load_words(a, rg, x0, x1, lane);
     seg_expand(a, k, rg, x0, x1, s_flag[wave], s_seg[wave], lane);
